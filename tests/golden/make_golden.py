@@ -1,0 +1,226 @@
+"""Generate golden vectors by running the REFERENCE itself (authoring container only).
+
+    python tests/golden/make_golden.py [case ...]      # default: all fast cases
+    python tests/golden/make_golden.py surface3d n8192 # slow cases (minutes each)
+
+The reference (/root/reference, scikit-learn 1.7.2 in this image) is imported with
+an empty stub for its missing third-party `Quaternion` module
+(policy_transportation.py:9).  Only inputs and outputs are written (npz, no
+pickles); the reference's sources are never copied.  The GPU box has no
+/root/reference: tests read the committed npz files only.
+"""
+import os
+import sys
+import types
+import warnings
+
+os.environ.setdefault("MPLBACKEND", "Agg")
+import numpy as np
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def import_reference():
+    sys.modules.setdefault("Quaternion", types.ModuleType("Quaternion"))
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    import policy_transportation as pt  # noqa
+    from policy_transportation.utils import resample
+    return pt, resample
+
+
+def kern(c, ls, noise):
+    from sklearn.gaussian_process.kernels import RBF, WhiteKernel, ConstantKernel as C
+    return C(c) * RBF(length_scale=ls) + WhiteKernel(noise)
+
+
+def theta_of(gp):
+    p = gp.kernel.get_params()
+    return dict(constant_value=np.float64(p["k1__k1__constant_value"]),
+                length_scale=np.atleast_1d(np.asarray(p["k1__k2__length_scale"], np.float64)),
+                noise_level=np.float64(p["k2__noise_level"]))
+
+
+def synthetic(N, M, seed=0, qseed=1, D=3):
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(0, 1, (N, D))
+    Y = 0.05 * np.sin(4 * X) + 0.01 * rng.standard_normal((N, D))
+    Xq = np.random.default_rng(qseed).uniform(-0.1, 1.1, (M, D))
+    return X, Y, Xq
+
+
+def gp_outputs(gp, Xq, with_L=True, with_cov=0, with_jvar=True):
+    out = {}
+    out["alpha_"] = gp.gp.alpha_
+    if with_L:
+        out["L_"] = gp.gp.L_
+    else:
+        out["L_diag"] = np.diag(gp.gp.L_).copy()
+        out["L_col0"] = gp.gp.L_[:, 0].copy()
+        out["L_lastrow"] = gp.gp.L_[-1, :].copy()
+    out["mean_only"] = gp.predict(Xq)
+    m, s = gp.predict(Xq, return_std=True)
+    out["mean"], out["std"] = m, s
+    if with_jvar:
+        J, Jv = gp.derivative(Xq, return_var=True)
+        out["J"], out["Jvar"] = J, Jv
+        out["dvar"] = gp.derivative_of_variance(Xq)
+    else:
+        out["J"] = gp.derivative(Xq)
+    if with_cov:
+        _, cov = gp.predict(Xq[:with_cov], return_cov=True)
+        out["cov"] = cov
+    out["noise_var_"] = np.float64(gp.noise_var_)
+    out["prior_var"] = np.float64(gp.prior_var)
+    return out
+
+
+def case_synthetic(pt, N, M, name, ls=(0.1, 0.1, 0.1), nan_rows=(), with_L=True, with_cov=0,
+                   with_jvar=True, lml=True):
+    X, Y, Xq = synthetic(N, M)
+    Y = Y.copy()
+    for r in nan_rows:
+        Y[r, r % 3] = np.nan
+    gp = pt.GaussianProcess(kernel=kern(0.1, list(ls), 1e-4), optimizer=None)
+    gp.fit(X, Y)
+    out = dict(X=X, Y=Y, Xq=Xq, alpha=np.float64(1e-10), **theta_of(gp))
+    out.update(gp_outputs(gp, Xq, with_L=with_L, with_cov=with_cov, with_jvar=with_jvar))
+    out["n_samples"] = np.int64(gp.n_samples)
+    if lml and not nan_rows:
+        thetas = []
+        vals = []
+        grads = []
+        base = gp.gp.kernel_.theta.copy()
+        rs = np.random.default_rng(7)
+        for k in range(3):
+            th = base + (0.0 if k == 0 else 1.0) * rs.normal(0, 0.3, base.shape)
+            v, g = gp.gp.log_marginal_likelihood(th, eval_gradient=True)
+            thetas.append(th); vals.append(v); grads.append(g)
+        out["lml_theta"] = np.array(thetas)
+        out["lml_value"] = np.array(vals)
+        out["lml_grad"] = np.array(grads)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, {k: np.shape(v) for k, v in out.items()})
+
+
+def case_letterS(pt, resample):
+    data = np.load(os.path.join(REF, "example/2D/data/example.npz"))
+    X = resample(data["demo"], num_points=400)
+    src = resample(data["floor"], num_points=20)
+    tgt = resample(data["newfloor"], num_points=20)
+    dX = np.zeros((len(X), 2))
+    dX[:-1] = X[1:] - X[:-1]
+    np.random.seed(0)            # sklearn's optimizer restarts use the global RNG (_gpr.py:248,319-330)
+    tr = pt.GaussianProcessTransportation(kernel_transport=kern(10, 4 * np.ones(2), 0.01))
+    tr.source_distribution = src
+    tr.target_distribution = tgt
+    tr.training_traj = X
+    tr.training_delta = dX
+    tr.fit_transportation(do_scale=False, do_rotation=True)
+    tr.apply_transportation()
+    gp = tr.method.delta_map
+    out = dict(demo_raw=data["demo"], floor_raw=data["floor"], newfloor_raw=data["newfloor"],
+               demo=X, source=src, target=tgt, delta=dX,
+               rotation=tr.method.affine_transform.rotation_matrix,
+               scale=np.float64(tr.method.affine_transform.scale),
+               S_centroid=tr.method.affine_transform.S_centroid,
+               T_centroid=tr.method.affine_transform.T_centroid,
+               traj=tr.training_traj, std=tr.std, vel=tr.training_delta,
+               var_vel=tr.var_vel_transported, alpha_=gp.gp.alpha_, L_=gp.gp.L_,
+               gp_X=gp.X, gp_Y=gp.Y, theta0=gp.gp.kernel.theta, theta_fit=gp.gp.kernel_.theta,
+               bounds=gp.gp.kernel.bounds, lml_fit=np.float64(gp.gp.log_marginal_likelihood_value_),
+               noise_var_=np.float64(gp.noise_var_), alpha=np.float64(1e-10), **theta_of(gp))
+    # second transport with do_scale=True, fixed hyper-parameters (affine scale branch)
+    np.random.seed(0)
+    tr2 = pt.GaussianProcessTransportation(kernel_transport=kern(out["constant_value"],
+                                                                 out["length_scale"], out["noise_level"]))
+    tr2.method.delta_map = pt.GaussianProcess(kernel=kern(out["constant_value"], out["length_scale"],
+                                                          out["noise_level"]), optimizer=None)
+    tr2.source_distribution = src
+    tr2.target_distribution = tgt
+    tr2.training_traj = X
+    tr2.training_delta = dX
+    tr2.fit_transportation(do_scale=True, do_rotation=True)
+    tr2.apply_transportation()
+    out.update(scale2=np.float64(tr2.method.affine_transform.scale), traj2=tr2.training_traj,
+               std2=tr2.std, vel2=tr2.training_delta, var_vel2=tr2.var_vel_transported)
+    np.savez_compressed(os.path.join(HERE, "letterS_2d.npz"), **out)
+    print("wrote letterS_2d", out["length_scale"], out["constant_value"], out["noise_var_"])
+
+
+def case_surface3d(pt, optimize=True):
+    """example/3D/surface_generalization_3D.py:50-61 flow (N=2500, default kernel).
+    optimizer on takes ~5 min here; the fitted theta is stored and outputs come from
+    a refit with optimizer=None at that theta (identical L_/alpha_ by construction)."""
+    data = np.load(os.path.join(REF, "example/3D/data/example.npz"))
+    X = data["demo"]
+    src = data["old_surface"].reshape(-1, 3)
+    tgt = data["new_surface"].reshape(-1, 3)
+    dX = np.zeros((len(X), 3))
+    dX[:-1] = X[1:] - X[:-1]
+    np.random.seed(0)
+    tr = pt.GaussianProcessTransportation()
+    if not optimize:
+        tr.method.delta_map = pt.GaussianProcess(kernel=kern(0.1, [0.1], 1e-4), optimizer=None)
+    tr.source_distribution = src
+    tr.target_distribution = tgt
+    tr.training_traj = X
+    tr.training_delta = dX
+    tr.fit_transportation()
+    tr.apply_transportation()
+    gp = tr.method.delta_map
+    out = dict(demo=X, source=src, target=tgt, delta=dX,
+               rotation=tr.method.affine_transform.rotation_matrix,
+               traj=tr.training_traj, std=tr.std, vel=tr.training_delta,
+               var_vel=tr.var_vel_transported, alpha_=gp.gp.alpha_,
+               theta_fit=gp.gp.kernel_.theta, lml_fit=np.float64(gp.gp.log_marginal_likelihood_value_),
+               noise_var_=np.float64(gp.noise_var_), alpha=np.float64(1e-10),
+               optimized=np.bool_(optimize), **theta_of(gp))
+    np.savez_compressed(os.path.join(HERE, "surface_3d.npz"), **out)
+    print("wrote surface_3d", out["length_scale"], out["constant_value"], out["noise_level"])
+
+
+def case_n8192(pt):
+    """N=8192 spot check, 256 queries (reference: ~30 s fit + minutes for Jvar)."""
+    X, Y, Xq = synthetic(8192, 256)
+    gp = pt.GaussianProcess(kernel=kern(0.1, [0.1] * 3, 1e-4), optimizer=None)
+    gp.fit(X, Y)
+    m, s = gp.predict(Xq, return_std=True)
+    J, Jv = gp.derivative(Xq, return_var=True)
+    g = gp.derivative_of_variance(Xq)
+    L = gp.gp.L_
+    out = dict(N=np.int64(8192), Xq=Xq, mean=m, std=s, J=J, Jvar=Jv, dvar=g,
+               alpha_=gp.gp.alpha_, L_diag=np.diag(L).copy(), L_col0=L[:, 0].copy(),
+               L_lastrow=L[-1].copy(), alpha=np.float64(1e-10), **theta_of(gp))
+    np.savez_compressed(os.path.join(HERE, "synthetic_3d_N8192.npz"), **out)
+    print("wrote synthetic_3d_N8192")
+
+
+def main(argv):
+    warnings.filterwarnings("ignore")
+    pt, resample = import_reference()
+    cases = argv or ["n64", "n64iso", "n64nan", "n256", "n1024", "letterS"]
+    for c in cases:
+        if c == "n64":
+            case_synthetic(pt, 64, 48, "synthetic_3d_N64", with_cov=16)
+        elif c == "n64iso":
+            case_synthetic(pt, 64, 48, "synthetic_3d_N64_iso", ls=(0.15,), with_cov=8)
+        elif c == "n64nan":
+            case_synthetic(pt, 64, 48, "synthetic_3d_N64_nan", nan_rows=(3, 17, 40))
+        elif c == "n256":
+            case_synthetic(pt, 256, 96, "synthetic_3d_N256")
+        elif c == "n1024":
+            case_synthetic(pt, 1024, 128, "synthetic_3d_N1024", with_L=False)
+        elif c == "letterS":
+            case_letterS(pt, resample)
+        elif c == "surface3d":
+            case_surface3d(pt, optimize=True)
+        elif c == "n8192":
+            case_n8192(pt)
+        else:
+            raise SystemExit("unknown case " + c)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])
