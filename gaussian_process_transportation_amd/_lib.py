@@ -1,0 +1,205 @@
+"""ctypes binding of libgpt_hip.so (include/gpt_hip.h).  No CPU fallback: if the library or a
+GPU is missing, every compute entry point raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgpt_hip.so")
+
+GPT_OK, GPT_E_HIP, GPT_E_NOT_PD, GPT_E_ARG, GPT_E_STATE = 0, -1, -2, -3, -4
+
+_dp = C.POINTER(C.c_double)
+_vp = C.c_void_p
+_i64 = C.c_int64
+
+# name -> (restype, argtypes); mirrors include/gpt_hip.h one to one
+SIGNATURES = {
+    "gpt_device_count": (C.c_int, []),
+    "gpt_last_error": (C.c_char_p, []),
+    "gpt_version": (C.c_char_p, []),
+    "gpt_create": (C.c_int, [C.POINTER(_vp), C.c_int]),
+    "gpt_destroy": (None, [_vp]),
+    "gpt_set_stream": (C.c_int, [_vp, _vp]),
+    "gpt_synchronize": (C.c_int, [_vp]),
+    "gpt_fit": (C.c_int, [_vp, _dp, _dp, _i64, C.c_int, C.c_int, _dp, C.c_int, C.c_double, C.c_double, C.c_double]),
+    "gpt_predict": (C.c_int, [_vp, _dp, _i64, _dp, _dp]),
+    "gpt_derivative": (C.c_int, [_vp, _dp, _i64, _dp, _dp]),
+    "gpt_dvariance": (C.c_int, [_vp, _dp, _i64, _dp]),
+    "gpt_predict_all": (C.c_int, [_vp, _dp, _i64, _dp, _dp, _dp, _dp, _dp]),
+    "gpt_predict_all_dev": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "gpt_export": (C.c_int, [_vp, _dp, _dp]),
+    "gpt_export_inverse_factor": (C.c_int, [_vp, _dp]),
+    "gpt_lml": (C.c_int, [_vp, _dp]),
+    "gpt_factor_blob": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
+    "gpt_factor_alloc": (C.c_int, [_vp, _i64, C.c_int, C.c_int, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
+    "gpt_factor_commit": (C.c_int, [_vp]),
+    "gpt_info": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_i64)]),
+    "gpt_fit_timings": (C.c_int, [_vp, _dp, C.c_int]),
+}
+
+_lib = None
+
+
+class GptError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libgpt_hip.so (built by `__graft_entry__.build()` / csrc/Makefile).  Fails loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
+            "or make -C gaussian_process_transportation_amd/csrc).  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the ABI drifted
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().gpt_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int, what: str = ""):
+    if rc == GPT_OK:
+        return
+    msg = last_error()
+    if rc == GPT_E_NOT_PD:
+        raise np.linalg.LinAlgError(msg)          # what sklearn raises (_gpr.py:348-358)
+    if rc == GPT_E_ARG:
+        raise ValueError(msg)
+    raise GptError(f"{what or 'libgpt_hip'} failed ({rc}): {msg}")
+
+
+def require_gpu() -> int:
+    n = load().gpt_device_count()
+    if n < 1:
+        raise GptError("no HIP device visible: this package only runs on an MI355X (gfx950); there is no CPU path")
+    return n
+
+
+def as_f64(a, ndim=None) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if ndim is not None and a.ndim != ndim:
+        raise ValueError(f"expected a {ndim}-D array, got shape {a.shape}")
+    return a
+
+
+def dptr(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+class Handle:
+    """Owns one gpt_handle (one fitted model on one GPU)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load()
+        require_gpu()
+        h = _vp()
+        check(self.lib.gpt_create(C.byref(h), int(device)), "gpt_create")
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.gpt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- fit / export
+    def fit(self, X, Y, length_scale, constant_value, noise_level, alpha):
+        X = as_f64(X, 2)
+        Y = as_f64(Y, 2)
+        ls = as_f64(np.atleast_1d(length_scale), 1)
+        N, D = X.shape
+        if Y.shape[0] != N:
+            raise ValueError("X and Y have different numbers of rows")
+        check(self.lib.gpt_fit(self._h, dptr(X), dptr(Y), N, D, Y.shape[1], dptr(ls), ls.size,
+                               float(constant_value), float(noise_level), float(alpha)), "gpt_fit")
+
+    def info(self):
+        N, NP, D, O = _i64(), _i64(), C.c_int(), C.c_int()
+        check(self.lib.gpt_info(self._h, C.byref(N), C.byref(D), C.byref(O), C.byref(NP)), "gpt_info")
+        return N.value, D.value, O.value, NP.value
+
+    def export(self, want_L=True, want_alpha=True):
+        N, D, O, _ = self.info()
+        L = np.empty((N, N)) if want_L else None
+        a = np.empty((N, O)) if want_alpha else None
+        check(self.lib.gpt_export(self._h, dptr(L), dptr(a)), "gpt_export")
+        return L, a
+
+    def export_inverse_factor(self):
+        N = self.info()[0]
+        W = np.empty((N, N))
+        check(self.lib.gpt_export_inverse_factor(self._h, dptr(W)), "gpt_export_inverse_factor")
+        return W
+
+    def lml(self) -> float:
+        v = C.c_double()
+        check(self.lib.gpt_lml(self._h, C.byref(v)), "gpt_lml")
+        return v.value
+
+    def fit_timings(self):
+        t = np.zeros(6)
+        check(self.lib.gpt_fit_timings(self._h, dptr(t), 6), "gpt_fit_timings")
+        return dict(zip(["total", "gram", "cholesky", "inverse", "alpha", "pack"], t.tolist()))
+
+    # ---- predict (host buffers)
+    def predict_all(self, Xq, mean=False, var=False, J=False, Jvar=False, dvar=False):
+        N, D, O, _ = self.info()
+        Xq = as_f64(Xq, 2)
+        if Xq.shape[1] != D:
+            raise ValueError(f"query has {Xq.shape[1]} features, model was fitted with {D}")
+        M = Xq.shape[0]
+        out = {
+            "mean": np.empty((M, O)) if mean else None,
+            "var": np.empty(M) if var else None,
+            "J": np.empty((M, O, D)) if J else None,
+            "Jvar": np.empty((M, D)) if Jvar else None,
+            "dvar": np.empty((D, M)) if dvar else None,
+        }
+        check(self.lib.gpt_predict_all(self._h, dptr(Xq), M, dptr(out["mean"]), dptr(out["var"]), dptr(out["J"]),
+                                       dptr(out["Jvar"]), dptr(out["dvar"])), "gpt_predict_all")
+        return out
+
+    # ---- predict (device pointers, asynchronous)
+    def predict_all_dev(self, xq_ptr, M, mean_ptr=0, var_ptr=0, J_ptr=0, Jvar_ptr=0, dvar_ptr=0):
+        check(self.lib.gpt_predict_all_dev(self._h, _vp(xq_ptr), int(M), _vp(mean_ptr or None), _vp(var_ptr or None),
+                                           _vp(J_ptr or None), _vp(Jvar_ptr or None), _vp(dvar_ptr or None)),
+              "gpt_predict_all_dev")
+
+    def set_stream(self, stream_ptr):
+        check(self.lib.gpt_set_stream(self._h, _vp(stream_ptr or None)), "gpt_set_stream")
+
+    def synchronize(self):
+        check(self.lib.gpt_synchronize(self._h), "gpt_synchronize")
+
+    # ---- multi-GPU hand-off
+    def factor_blob(self):
+        p, n = _vp(), C.c_size_t()
+        check(self.lib.gpt_factor_blob(self._h, C.byref(p), C.byref(n)), "gpt_factor_blob")
+        return p.value, n.value
+
+    def factor_alloc(self, N, D, O):
+        p, n = _vp(), C.c_size_t()
+        check(self.lib.gpt_factor_alloc(self._h, int(N), int(D), int(O), C.byref(p), C.byref(n)), "gpt_factor_alloc")
+        return p.value, n.value
+
+    def factor_commit(self):
+        check(self.lib.gpt_factor_commit(self._h), "gpt_factor_commit")

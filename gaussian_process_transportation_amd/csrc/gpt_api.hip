@@ -1,0 +1,450 @@
+// C ABI of libgpt_hip (see include/gpt_hip.h).  Host-side orchestration only: owns the device
+// buffers, prepares scaled/padded inputs, sequences the kernels of gpt_fit.hip / gpt_predict.hip
+// on one HIP stream and maps failures to error codes.
+#include "gpt_common.h"
+#include "../../include/gpt_hip.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace gpt;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(GPT_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));            \
+    } while (0)
+
+constexpr double MAGIC = 1196446769.0;   // "GPT1"
+constexpr int HDR_DOUBLES = 64;
+constexpr int64_t HOST_CHUNK = 1 << 18;  // queries per pass of the host-pointer API
+
+struct Layout {
+    int64_t N, NP;
+    int D, O, npass;
+    size_t off_xs, off_a4, off_wf, total;   // in doubles
+};
+
+Layout make_layout(int64_t N, int D, int O) {
+    Layout l;
+    l.N = N; l.D = D; l.O = O;
+    l.NP = (N + PAD_N - 1) / PAD_N * PAD_N;
+    l.npass = (O + 3) / 4;
+    l.off_xs = HDR_DOUBLES;
+    l.off_a4 = l.off_xs + (size_t)l.NP * 4;
+    l.off_wf = l.off_a4 + (size_t)l.npass * l.NP * 4;
+    l.total = l.off_wf + wf_doubles((int)l.NP);
+    return l;
+}
+
+}  // namespace
+
+struct gpt_handle {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    // model blob
+    double* blob = nullptr;
+    Layout lay{};
+    bool have_layout = false, committed = false;
+    KernelParams p{};
+    double jitter = 0, ls[3] = {1, 1, 1};
+    int n_ls = 1;
+    // fit workspace
+    double *dK = nullptr, *dW = nullptr, *dY4 = nullptr, *dT4 = nullptr, *dscal = nullptr;
+    int* dinfo = nullptr;
+    int64_t ws_np = 0;
+    int ws_npass = 0;
+    bool have_factor_ws = false;   // dK/dW hold L / L^-1 of the current model
+    std::vector<double> hostY;     // filtered targets (N,O) for the LML
+    // staging of the host-pointer API
+    double *sq = nullptr, *smean = nullptr, *svar = nullptr, *sJ = nullptr, *sJvar = nullptr, *sdvar = nullptr;
+    int64_t scap = 0;
+    int sD = 0, sO = 0;
+    double fit_ms[6] = {0, 0, 0, 0, 0, 0};
+    hipEvent_t ev[7] = {};
+
+    double* dXs() const { return blob + lay.off_xs; }
+    double* dA4() const { return blob + lay.off_a4; }
+    double* dWf() const { return blob + lay.off_wf; }
+};
+
+namespace {
+
+int set_device(gpt_handle* h) {
+    HIPCHK(hipSetDevice(h->device));
+    return GPT_OK;
+}
+
+void free_staging(gpt_handle* h) {
+    double** ptrs[] = {&h->sq, &h->smean, &h->svar, &h->sJ, &h->sJvar, &h->sdvar};
+    for (auto pp : ptrs) { if (*pp) (void)hipFree(*pp); *pp = nullptr; }
+    h->scap = 0;
+}
+
+void free_workspace(gpt_handle* h) {
+    double** ptrs[] = {&h->dK, &h->dW, &h->dY4, &h->dT4, &h->dscal};
+    for (auto pp : ptrs) { if (*pp) (void)hipFree(*pp); *pp = nullptr; }
+    if (h->dinfo) (void)hipFree(h->dinfo);
+    h->dinfo = nullptr;
+    h->ws_np = 0; h->ws_npass = 0; h->have_factor_ws = false;
+}
+
+int ensure_blob(gpt_handle* h, const Layout& l) {
+    if (h->blob && h->have_layout && h->lay.total == l.total && h->lay.NP == l.NP && h->lay.npass == l.npass) {
+        h->lay = l;
+        return GPT_OK;
+    }
+    if (h->blob) { (void)hipFree(h->blob); h->blob = nullptr; }
+    HIPCHK(hipMalloc(&h->blob, l.total * sizeof(double)));
+    h->lay = l;
+    h->have_layout = true;
+    return GPT_OK;
+}
+
+int ensure_workspace(gpt_handle* h, int64_t NP, int npass) {
+    if (h->ws_np == NP && h->ws_npass >= npass && h->dK) return GPT_OK;
+    free_workspace(h);
+    HIPCHK(hipMalloc(&h->dK, (size_t)NP * NP * sizeof(double)));
+    HIPCHK(hipMalloc(&h->dW, (size_t)NP * NP * sizeof(double)));
+    HIPCHK(hipMalloc(&h->dY4, (size_t)npass * NP * 4 * sizeof(double)));
+    HIPCHK(hipMalloc(&h->dT4, (size_t)NP * 4 * sizeof(double)));
+    HIPCHK(hipMalloc(&h->dscal, 8 * sizeof(double)));
+    HIPCHK(hipMalloc(&h->dinfo, sizeof(int)));
+    h->ws_np = NP; h->ws_npass = npass;
+    return GPT_OK;
+}
+
+int ensure_staging(gpt_handle* h, int64_t cap, int D, int O) {
+    if (h->scap >= cap && h->sD == D && h->sO == O) return GPT_OK;
+    free_staging(h);
+    HIPCHK(hipMalloc(&h->sq, (size_t)cap * D * sizeof(double)));
+    HIPCHK(hipMalloc(&h->smean, (size_t)cap * O * sizeof(double)));
+    HIPCHK(hipMalloc(&h->svar, (size_t)cap * sizeof(double)));
+    HIPCHK(hipMalloc(&h->sJ, (size_t)cap * O * D * sizeof(double)));
+    HIPCHK(hipMalloc(&h->sJvar, (size_t)cap * D * sizeof(double)));
+    HIPCHK(hipMalloc(&h->sdvar, (size_t)cap * D * sizeof(double)));
+    h->scap = cap; h->sD = D; h->sO = O;
+    return GPT_OK;
+}
+
+void fill_params(gpt_handle* h, const double* hdr) {
+    KernelParams& p = h->p;
+    p.N = (int)hdr[1]; p.NP = (int)hdr[2]; p.D = (int)hdr[3]; p.O = (int)hdr[4];
+    p.c = hdr[5]; p.noise = hdr[6];
+    h->jitter = hdr[7];
+    h->n_ls = (int)hdr[11];
+    for (int d = 0; d < 3; ++d) {
+        h->ls[d] = hdr[8 + d];
+        p.inv_ls[d] = (d < p.D) ? 1.0 / hdr[8 + d] : 0.0;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int gpt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* gpt_last_error(void) { return g_err.c_str(); }
+const char* gpt_version(void) { return "gpt_hip 0.1 (gfx950)"; }
+
+int gpt_create(gpt_handle** out, int device) {
+    if (!out) return fail(GPT_E_ARG, "gpt_create: out is NULL");
+    int n = gpt_device_count();
+    if (device < 0 || device >= n) return fail(GPT_E_ARG, "gpt_create: no such HIP device");
+    HIPCHK(hipSetDevice(device));
+    gpt_handle* h = new gpt_handle();
+    h->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete h; return fail(GPT_E_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
+    h->stream = h->own_stream;
+    for (auto& ev : h->ev) {
+        e = hipEventCreate(&ev);
+        if (e != hipSuccess) { delete h; return fail(GPT_E_HIP, std::string("hipEventCreate: ") + hipGetErrorString(e)); }
+    }
+    *out = h;
+    return GPT_OK;
+}
+
+void gpt_destroy(gpt_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    free_staging(h);
+    free_workspace(h);
+    if (h->blob) (void)hipFree(h->blob);
+    for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+}
+
+int gpt_set_stream(gpt_handle* h, void* hip_stream) {
+    if (!h) return fail(GPT_E_ARG, "gpt_set_stream: NULL handle");
+    h->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : h->own_stream;
+    return GPT_OK;
+}
+
+int gpt_synchronize(gpt_handle* h) {
+    if (!h) return fail(GPT_E_ARG, "gpt_synchronize: NULL handle");
+    if (int rc = set_device(h)) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return GPT_OK;
+}
+
+int gpt_fit(gpt_handle* h, const double* X, const double* Y, int64_t N, int D, int O,
+            const double* length_scale, int n_ls, double constant_value, double noise_level,
+            double alpha_jitter) {
+    if (!h || !X || !Y || !length_scale) return fail(GPT_E_ARG, "gpt_fit: NULL argument");
+    if (N < 1 || N > (1 << 20)) return fail(GPT_E_ARG, "gpt_fit: N out of range");
+    if (D < 1 || D > 3) return fail(GPT_E_ARG, "gpt_fit: D must be 1, 2 or 3");
+    if (O < 1) return fail(GPT_E_ARG, "gpt_fit: O must be >= 1");
+    if (n_ls != 1 && n_ls != D) return fail(GPT_E_ARG, "gpt_fit: length_scale must have 1 or D entries");
+    for (int d = 0; d < n_ls; ++d)
+        if (!(length_scale[d] > 0.0)) return fail(GPT_E_ARG, "gpt_fit: length_scale must be > 0");
+    if (!(constant_value > 0.0) || !(noise_level >= 0.0) || !(alpha_jitter >= 0.0))
+        return fail(GPT_E_ARG, "gpt_fit: constant_value > 0, noise_level >= 0, alpha >= 0 required");
+    if (int rc = set_device(h)) return rc;
+    h->committed = false;
+    const Layout l = make_layout(N, D, O);
+    if (int rc = ensure_blob(h, l)) return rc;
+    if (int rc = ensure_workspace(h, l.NP, l.npass)) return rc;
+    const int NP = (int)l.NP;
+    hipStream_t s = h->stream;
+
+    // ---- host preparation: header, scaled + padded sources, padded targets
+    std::vector<double> hdr(HDR_DOUBLES, 0.0);
+    hdr[0] = MAGIC; hdr[1] = (double)N; hdr[2] = (double)NP; hdr[3] = D; hdr[4] = O;
+    hdr[5] = constant_value; hdr[6] = noise_level; hdr[7] = alpha_jitter;
+    for (int d = 0; d < 3; ++d) hdr[8 + d] = (d < D) ? length_scale[n_ls == 1 ? 0 : d] : 1.0;
+    hdr[11] = n_ls; hdr[12] = l.npass;
+    fill_params(h, hdr.data());
+    std::vector<double> xs((size_t)NP * 4, 0.0), y4((size_t)l.npass * NP * 4, 0.0);
+    for (int64_t i = 0; i < N; ++i) {
+        for (int d = 0; d < D; ++d) xs[(size_t)i * 4 + d] = X[i * D + d] * h->p.inv_ls[d];
+        for (int o = 0; o < O; ++o) y4[((size_t)(o / 4) * NP + i) * 4 + (o % 4)] = Y[i * O + o];
+    }
+    h->hostY.assign(Y, Y + (size_t)N * O);
+    HIPCHK(hipMemcpyAsync(h->blob, hdr.data(), HDR_DOUBLES * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->dXs(), xs.data(), xs.size() * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->dY4, y4.data(), y4.size() * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));   // host vectors go out of scope below
+
+    // ---- device pipeline
+    HIPCHK(hipEventRecord(h->ev[0], s));
+    HIPCHK(hipMemsetAsync(h->dinfo, 0, sizeof(int), s));
+    HIPCHK(hipMemsetAsync(h->dW, 0, (size_t)NP * NP * sizeof(double), s));
+    launch_gram(s, h->dXs(), (int)N, NP, constant_value, noise_level + alpha_jitter, h->dK);
+    HIPCHK(hipEventRecord(h->ev[1], s));
+    launch_potrf(s, h->dK, h->dW, NP, h->dinfo);
+    HIPCHK(hipEventRecord(h->ev[2], s));
+    launch_trinv(s, h->dK, h->dW, NP, h->dWf());
+    HIPCHK(hipEventRecord(h->ev[3], s));
+    for (int ps = 0; ps < l.npass; ++ps)
+        launch_alpha(s, h->dW, h->dY4 + (size_t)ps * NP * 4, (int)N, NP, h->dT4, h->dA4() + (size_t)ps * NP * 4);
+    HIPCHK(hipEventRecord(h->ev[4], s));
+    launch_pack_w(s, h->dW, (int)N, NP, h->dWf());
+    HIPCHK(hipEventRecord(h->ev[5], s));
+    HIPCHK(hipGetLastError());
+    int info = 0;
+    HIPCHK(hipMemcpyAsync(&info, h->dinfo, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    float ms = 0;
+    for (int i = 1; i <= 5; ++i) {
+        HIPCHK(hipEventElapsedTime(&ms, h->ev[i - 1], h->ev[i]));
+        h->fit_ms[i] = ms;
+    }
+    HIPCHK(hipEventElapsedTime(&ms, h->ev[0], h->ev[5]));
+    h->fit_ms[0] = ms;
+    if (info != 0) {
+        h->have_factor_ws = false;
+        char buf[160];
+        snprintf(buf, sizeof buf, "gpt_fit: kernel matrix is not positive definite (pivot %d <= 0)", info);
+        return fail(GPT_E_NOT_PD, buf);
+    }
+    h->committed = true;
+    h->have_factor_ws = true;
+    return GPT_OK;
+}
+
+int gpt_predict_all_dev(gpt_handle* h, const double* Xq, int64_t M, double* mean, double* var,
+                        double* J, double* Jvar, double* dvar) {
+    if (!h) return fail(GPT_E_ARG, "gpt_predict_all_dev: NULL handle");
+    if (!h->committed) return fail(GPT_E_STATE, "predict: model is not fitted");
+    if (M < 0 || (M > 0 && !Xq)) return fail(GPT_E_ARG, "predict: bad query buffer");
+    if (M == 0) return GPT_OK;
+    if (int rc = set_device(h)) return rc;
+    hipStream_t s = h->stream;
+    if (mean || J) launch_mean_jac(s, h->p, h->dXs(), h->dA4(), Xq, M, mean, J);
+    if (Jvar || dvar) launch_var(s, h->p, h->dXs(), h->dWf(), Xq, M, 4, var, Jvar, dvar);
+    else if (var) launch_var(s, h->p, h->dXs(), h->dWf(), Xq, M, 1, var, nullptr, nullptr);
+    HIPCHK(hipGetLastError());
+    return GPT_OK;
+}
+
+int gpt_predict_all(gpt_handle* h, const double* Xq, int64_t M, double* mean, double* var,
+                    double* J, double* Jvar, double* dvar) {
+    if (!h) return fail(GPT_E_ARG, "gpt_predict_all: NULL handle");
+    if (!h->committed) return fail(GPT_E_STATE, "predict: model is not fitted");
+    if (M < 0 || (M > 0 && !Xq)) return fail(GPT_E_ARG, "predict: bad query buffer");
+    if (M == 0) return GPT_OK;
+    if (int rc = set_device(h)) return rc;
+    const int D = h->p.D, O = h->p.O;
+    const int64_t cap = M < HOST_CHUNK ? M : HOST_CHUNK;
+    if (int rc = ensure_staging(h, cap, D, O)) return rc;
+    hipStream_t s = h->stream;
+    for (int64_t off = 0; off < M; off += cap) {
+        const int64_t m = (M - off) < cap ? (M - off) : cap;
+        HIPCHK(hipMemcpyAsync(h->sq, Xq + off * D, (size_t)m * D * sizeof(double), hipMemcpyHostToDevice, s));
+        int rc = gpt_predict_all_dev(h, h->sq, m, mean ? h->smean : nullptr, var ? h->svar : nullptr,
+                                     J ? h->sJ : nullptr, Jvar ? h->sJvar : nullptr, dvar ? h->sdvar : nullptr);
+        if (rc) return rc;
+        if (mean) HIPCHK(hipMemcpyAsync(mean + off * O, h->smean, (size_t)m * O * sizeof(double), hipMemcpyDeviceToHost, s));
+        if (var) HIPCHK(hipMemcpyAsync(var + off, h->svar, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, s));
+        if (J) HIPCHK(hipMemcpyAsync(J + off * O * D, h->sJ, (size_t)m * O * D * sizeof(double), hipMemcpyDeviceToHost, s));
+        if (Jvar) HIPCHK(hipMemcpyAsync(Jvar + off * D, h->sJvar, (size_t)m * D * sizeof(double), hipMemcpyDeviceToHost, s));
+        if (dvar)
+            for (int d = 0; d < D; ++d)   // device chunk is (D, m); host result is (D, M)
+                HIPCHK(hipMemcpyAsync(dvar + (size_t)d * M + off, h->sdvar + (size_t)d * m, (size_t)m * sizeof(double),
+                                      hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    return GPT_OK;
+}
+
+int gpt_predict(gpt_handle* h, const double* Xq, int64_t M, double* mean, double* var) {
+    return gpt_predict_all(h, Xq, M, mean, var, nullptr, nullptr, nullptr);
+}
+
+int gpt_derivative(gpt_handle* h, const double* Xq, int64_t M, double* J, double* Jvar) {
+    return gpt_predict_all(h, Xq, M, nullptr, nullptr, J, Jvar, nullptr);
+}
+
+int gpt_dvariance(gpt_handle* h, const double* Xq, int64_t M, double* g) {
+    return gpt_predict_all(h, Xq, M, nullptr, nullptr, nullptr, nullptr, g);
+}
+
+int gpt_export(gpt_handle* h, double* L, double* alpha) {
+    if (!h) return fail(GPT_E_ARG, "gpt_export: NULL handle");
+    if (!h->committed) return fail(GPT_E_STATE, "gpt_export: model is not fitted");
+    if (int rc = set_device(h)) return rc;
+    const int64_t N = h->p.N, NP = h->p.NP;
+    const int O = h->p.O;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (L) {
+        if (!h->have_factor_ws) return fail(GPT_E_STATE, "gpt_export: L is only available on the rank that ran gpt_fit");
+        HIPCHK(hipMemcpy2D(L, (size_t)N * sizeof(double), h->dK, (size_t)NP * sizeof(double), (size_t)N * sizeof(double),
+                           (size_t)N, hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < N; ++i)
+            for (int64_t j = i + 1; j < N; ++j) L[i * N + j] = 0.0;
+    }
+    if (alpha) {
+        std::vector<double> a4((size_t)h->lay.npass * NP * 4);
+        HIPCHK(hipMemcpy(a4.data(), h->dA4(), a4.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < N; ++i)
+            for (int o = 0; o < O; ++o) alpha[i * O + o] = a4[((size_t)(o / 4) * NP + i) * 4 + (o % 4)];
+    }
+    return GPT_OK;
+}
+
+int gpt_export_inverse_factor(gpt_handle* h, double* W) {
+    if (!h || !W) return fail(GPT_E_ARG, "gpt_export_inverse_factor: NULL argument");
+    if (!h->committed || !h->have_factor_ws) return fail(GPT_E_STATE, "gpt_export_inverse_factor: no factor on this handle");
+    if (int rc = set_device(h)) return rc;
+    const int64_t N = h->p.N, NP = h->p.NP;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy2D(W, (size_t)N * sizeof(double), h->dW, (size_t)NP * sizeof(double), (size_t)N * sizeof(double),
+                       (size_t)N, hipMemcpyDeviceToHost));
+    return GPT_OK;
+}
+
+int gpt_lml(gpt_handle* h, double* lml) {
+    if (!h || !lml) return fail(GPT_E_ARG, "gpt_lml: NULL argument");
+    if (!h->committed || !h->have_factor_ws) return fail(GPT_E_STATE, "gpt_lml: needs the handle that ran gpt_fit");
+    if (int rc = set_device(h)) return rc;
+    const int64_t N = h->p.N, NP = h->p.NP;
+    const int O = h->p.O;
+    launch_logdet(h->stream, h->dK, (int)N, (int)NP, h->dscal);
+    double logdet = 0;
+    HIPCHK(hipMemcpyAsync(&logdet, h->dscal, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    std::vector<double> a4((size_t)h->lay.npass * NP * 4);
+    HIPCHK(hipMemcpyAsync(a4.data(), h->dA4(), a4.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    double total = 0;
+    for (int o = 0; o < O; ++o) {
+        double ya = 0;
+        for (int64_t i = 0; i < N; ++i) ya += h->hostY[i * O + o] * a4[((size_t)(o / 4) * NP + i) * 4 + (o % 4)];
+        total += -0.5 * ya - logdet - 0.5 * (double)N * std::log(2.0 * M_PI);
+    }
+    *lml = total;
+    return GPT_OK;
+}
+
+int gpt_factor_blob(gpt_handle* h, void** dev_ptr, size_t* bytes) {
+    if (!h || !dev_ptr || !bytes) return fail(GPT_E_ARG, "gpt_factor_blob: NULL argument");
+    if (!h->blob || !h->have_layout) return fail(GPT_E_STATE, "gpt_factor_blob: no model storage");
+    *dev_ptr = h->blob;
+    *bytes = h->lay.total * sizeof(double);
+    return GPT_OK;
+}
+
+int gpt_factor_alloc(gpt_handle* h, int64_t N, int D, int O, void** dev_ptr, size_t* bytes) {
+    if (!h || !dev_ptr || !bytes) return fail(GPT_E_ARG, "gpt_factor_alloc: NULL argument");
+    if (N < 1 || D < 1 || D > 3 || O < 1) return fail(GPT_E_ARG, "gpt_factor_alloc: bad geometry");
+    if (int rc = set_device(h)) return rc;
+    h->committed = false;
+    h->have_factor_ws = false;
+    if (int rc = ensure_blob(h, make_layout(N, D, O))) return rc;
+    *dev_ptr = h->blob;
+    *bytes = h->lay.total * sizeof(double);
+    return GPT_OK;
+}
+
+int gpt_factor_commit(gpt_handle* h) {
+    if (!h) return fail(GPT_E_ARG, "gpt_factor_commit: NULL handle");
+    if (!h->blob || !h->have_layout) return fail(GPT_E_STATE, "gpt_factor_commit: no model storage");
+    if (int rc = set_device(h)) return rc;
+    double hdr[HDR_DOUBLES];
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(hdr, h->blob, sizeof hdr, hipMemcpyDeviceToHost));
+    if (hdr[0] != MAGIC) return fail(GPT_E_STATE, "gpt_factor_commit: blob has no model header (broadcast missing?)");
+    if ((int64_t)hdr[1] != h->lay.N || (int)hdr[3] != h->lay.D || (int)hdr[4] != h->lay.O || (int64_t)hdr[2] != h->lay.NP)
+        return fail(GPT_E_STATE, "gpt_factor_commit: header geometry differs from gpt_factor_alloc");
+    fill_params(h, hdr);
+    h->committed = true;
+    return GPT_OK;
+}
+
+int gpt_info(gpt_handle* h, int64_t* N, int* D, int* O, int64_t* N_padded) {
+    if (!h) return fail(GPT_E_ARG, "gpt_info: NULL handle");
+    if (!h->committed) return fail(GPT_E_STATE, "gpt_info: model is not fitted");
+    if (N) *N = h->p.N;
+    if (D) *D = h->p.D;
+    if (O) *O = h->p.O;
+    if (N_padded) *N_padded = h->p.NP;
+    return GPT_OK;
+}
+
+int gpt_fit_timings(gpt_handle* h, double* ms_out, int n) {
+    if (!h || !ms_out) return fail(GPT_E_ARG, "gpt_fit_timings: NULL argument");
+    for (int i = 0; i < n && i < 6; ++i) ms_out[i] = h->fit_ms[i];
+    return GPT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,441 @@
+// Fit-side kernels for gfx950 (MI355X): RBF Gram assembly, blocked right-looking fp64
+// Cholesky with MFMA (v_mfma_f64_16x16x4_f64) panel/trailing updates, blocked triangular
+// inverse by recursive doubling, alpha = K^-1 Y, and packing of W = L^-1 into the
+// MFMA-fragment-ordered tile stream the variance kernel consumes.
+//
+// What is replaced (reference, all CPU/LAPACK): sklearn/_gpr.py:346-364 (kernel_(X), +alpha on
+// the diagonal, cholesky, cho_solve) and models/gaussian_process.py:42-43 (explicit K^-1, here
+// kept as its triangular factor W = L^-1 so that k^T K^-1 k = |W k|^2).
+#include "gpt_common.h"
+
+namespace gpt {
+
+// =====================================================================================
+// Gram assembly: K[i][j] = c * exp(-0.5 |xs_i - xs_j|^2) (+ diag_add on the diagonal) for the
+// block lower triangle; padded rows/cols get the identity so the factorisation stays PD.
+// HBM-write bound: one 64x64 tile per workgroup, 16 consecutive doubles per thread.
+// =====================================================================================
+__global__ __launch_bounds__(256) void k_gram(const double* __restrict__ Xs, int N, int NP, double c,
+                                              double diag_add, double* __restrict__ K) {
+    const int bi = blockIdx.y, bj = blockIdx.x;
+    if (bj > bi) return;
+    __shared__ double xi[64][3], xj[64][3];
+    const int t = threadIdx.x;
+    if (t < 64) {
+        const double* p = Xs + (size_t)(bi * 64 + t) * 4;
+        xi[t][0] = p[0]; xi[t][1] = p[1]; xi[t][2] = p[2];
+    } else if (t < 128) {
+        const double* p = Xs + (size_t)(bj * 64 + (t - 64)) * 4;
+        xj[t - 64][0] = p[0]; xj[t - 64][1] = p[1]; xj[t - 64][2] = p[2];
+    }
+    __syncthreads();
+    const int r = t >> 2, cs = (t & 3) * 16;
+    const int i = bi * 64 + r;
+    const double a0 = xi[r][0], a1 = xi[r][1], a2 = xi[r][2];
+    double* out = K + (size_t)i * NP + bj * 64 + cs;
+#pragma unroll
+    for (int u = 0; u < 16; u += 2) {
+        double v[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int cc = cs + u + e;
+            const int j = bj * 64 + cc;
+            const double d0 = a0 - xj[cc][0], d1 = a1 - xj[cc][1], d2 = a2 - xj[cc][2];
+            double val = c * exp(-0.5 * (d0 * d0 + d1 * d1 + d2 * d2));
+            if (i == j) val += diag_add;
+            if (i >= N || j >= N) val = (i == j) ? 1.0 : 0.0;
+            v[e] = val;
+        }
+        *reinterpret_cast<d2*>(out + u) = d2{v[0], v[1]};
+    }
+}
+
+void launch_gram(hipStream_t s, const double* Xs, int N, int NP, double c, double diag_add, double* K) {
+    dim3 grid(NP / 64, NP / 64);
+    hipLaunchKernelGGL(k_gram, grid, dim3(256), 0, s, Xs, N, NP, c, diag_add, K);
+}
+
+// =====================================================================================
+// Diagonal block: unblocked Cholesky of one NB x NB block in LDS + its triangular inverse.
+// One workgroup.  Writes L_kk into K (zeros above the diagonal) and L_kk^-1 into W.
+// A non-positive (or NaN) pivot records 1-based row index in *info (first failure wins)
+// and substitutes 1 so the kernel chain terminates without NaN storms.
+// =====================================================================================
+constexpr int DS = NB + 1;   // LDS row stride (doubles)
+
+__global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ K, double* __restrict__ W, int NP, int kb,
+                                                    int* __restrict__ info) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* A = smem;                 // [NB][DS]
+    double* X = smem + NB * DS;       // [NB][DS]
+    double* dsq = X + NB * DS;        // [NB]
+    double* dinv = dsq + NB;          // [NB]
+    const int t = threadIdx.x;
+    const int k0 = kb * NB;
+    for (int e = t; e < NB * NB; e += 256) {
+        const int r = e / NB, c = e % NB;
+        A[r * DS + c] = (c <= r) ? K[(size_t)(k0 + r) * NP + k0 + c] : 0.0;
+        X[r * DS + c] = 0.0;
+    }
+    const int ui = t >> 2, uc = t & 3;
+    for (int j = 0; j < NB; ++j) {
+        __syncthreads();
+        double d = A[j * DS + j];
+        if (!(d > 0.0)) {            // also catches NaN
+            if (t == 0) atomicCAS(info, 0, k0 + j + 1);
+            d = 1.0;
+        }
+        if (t == 0) { const double s = sqrt(d); dsq[j] = s; dinv[j] = 1.0 / s; }
+        if (ui > j) {
+            const double f = A[ui * DS + j] / d;
+            for (int c = j + 1 + ((uc - (j + 1)) & 3); c <= ui; c += 4) A[ui * DS + c] -= f * A[c * DS + j];
+        }
+    }
+    __syncthreads();
+    for (int e = t; e < NB * NB; e += 256) {
+        const int r = e / NB, c = e % NB;
+        double v = 0.0;
+        if (c < r) v = A[r * DS + c] * dinv[c];
+        else if (c == r) v = dsq[r];
+        A[r * DS + c] = v;
+    }
+    __syncthreads();
+    // inverse: thread c owns column c of X = L^-1 (forward substitution, uniform loop bounds)
+    if (t < NB) {
+        const int c = t;
+        for (int i = 0; i < NB; ++i) {
+            double s = (i == c) ? 1.0 : 0.0;
+            for (int k = 0; k < i; ++k) s -= A[i * DS + k] * X[k * DS + c];
+            X[i * DS + c] = (i >= c) ? s * dinv[i] : 0.0;
+        }
+    }
+    __syncthreads();
+    for (int e = t; e < NB * NB; e += 256) {
+        const int r = e / NB, c = e % NB;
+        K[(size_t)(k0 + r) * NP + k0 + c] = A[r * DS + c];
+        W[(size_t)(k0 + r) * NP + k0 + c] = X[r * DS + c];
+    }
+}
+
+// =====================================================================================
+// Generic fp64 MFMA GEMM, 128x128 output tile per workgroup (4 waves, 2x2, 64x64 each),
+// K consumed in LDS-staged chunks of 32:  C = alpha * A * op(B) + beta * C.
+//   BT = true : op(B) = B^T, B stored [n][k] row-major (SYRK / TRSM-by-inverse)
+//   BT = false: op(B) = B,   B stored [k][n] row-major (triangular-inverse products)
+// All dims are multiples of 64; partial 128-tiles are guarded per 64x64 wave quadrant.
+// LDS strides: [row][k] images use 34 doubles per row, [k][n] images 144 — both make the
+// 16x4 fragment reads (ds_read_b64, two 32-lane halves) bank-conflict free.
+// Batched over blockIdx.z with element strides; the last batch may have its own M / K.
+// =====================================================================================
+struct GemmArgs {
+    const double* A; long lda; long sA;
+    const double* B; long ldb; long sB;
+    double* C; long ldc; long sC;
+    int M, N, K;
+    int M_last, K_last;      // dims of the last batch entry (trinv partial pair)
+    int nbatch;
+    double alpha, beta;
+    int lower_only;          // skip tiles strictly above the block diagonal (SYRK)
+    int a_lower;             // A lower triangular: k < i0 + 128
+    int b_lower;             // B lower triangular (BT=false): k >= j0
+};
+
+constexpr int GA_S = 34;     // [row][k] stride
+constexpr int GB_S = 144;    // [k][n] stride
+
+template <bool BT>
+__global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* As = smem;                // [128][GA_S]
+    double* Bs = smem + 128 * GA_S;   // BT: [128][GA_S]   else: [32][GB_S]
+    const int b = blockIdx.z;
+    const bool last = (b == g.nbatch - 1);
+    const int M = last ? g.M_last : g.M;
+    const int K = last ? g.K_last : g.K;
+    const int N = g.N;
+    const int i0 = blockIdx.y * 128, j0 = blockIdx.x * 128;
+    if (i0 >= M || j0 >= N) return;
+    if (g.lower_only && j0 > i0) return;
+    const double* A = g.A + (size_t)b * g.sA;
+    const double* B = g.B + (size_t)b * g.sB;
+    double* C = g.C + (size_t)b * g.sC;
+    int kbeg = 0, kend = K;
+    if (g.a_lower) kend = min(K, i0 + 128);
+    if (g.b_lower) kbeg = j0;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int wr = w >> 1, wc = w & 1;
+    const int lc = lane & 15, lk = lane >> 4;
+    const bool active = (i0 + 64 * wr < M) && (j0 + 64 * wc < N) && !(g.lower_only && i0 == j0 && wc > wr);
+    d4 acc[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[r][c] = d4{0, 0, 0, 0};
+
+    for (int kc = kbeg; kc < kend; kc += 32) {
+        {   // A chunk: 128 rows x 32 k; thread -> row t>>1, 16 consecutive k
+            const int r = t >> 1, h = (t & 1) * 16;
+            const bool ok = (i0 + r) < M;
+            const d2* src = reinterpret_cast<const d2*>(A + (size_t)(i0 + r) * g.lda + kc + h);
+            d2* dst = reinterpret_cast<d2*>(&As[r * GA_S + h]);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) dst[u] = ok ? src[u] : d2{0, 0};
+        }
+        if (BT) {
+            const int r = t >> 1, h = (t & 1) * 16;
+            const bool ok = (j0 + r) < N;
+            const d2* src = reinterpret_cast<const d2*>(B + (size_t)(j0 + r) * g.ldb + kc + h);
+            d2* dst = reinterpret_cast<d2*>(&Bs[r * GA_S + h]);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) dst[u] = ok ? src[u] : d2{0, 0};
+        } else {
+            const int kr = t >> 3, sg = (t & 7) * 16;
+            const bool ok = (j0 + sg) < N;      // N multiple of 64 and sg multiple of 16
+            const d2* src = reinterpret_cast<const d2*>(B + (size_t)(kc + kr) * g.ldb + j0 + sg);
+            d2* dst = reinterpret_cast<d2*>(&Bs[kr * GB_S + sg]);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) dst[u] = ok ? src[u] : d2{0, 0};
+        }
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                double a[4], bb[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a[r] = As[(64 * wr + 16 * r + lc) * GA_S + 4 * s + lk];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    bb[c] = BT ? Bs[(64 * wc + 16 * c + lc) * GA_S + 4 * s + lk]
+                               : Bs[(4 * s + lk) * GB_S + 64 * wc + 16 * c + lc];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        acc[r][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r], bb[c], acc[r][c], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    if (!active) return;
+    const double alpha = g.alpha, beta = g.beta;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = i0 + 64 * wr + 16 * r + lk + 4 * e;
+                const int col = j0 + 64 * wc + 16 * c + lc;
+                double* p = C + (size_t)row * g.ldc + col;
+                double v = alpha * acc[r][c][e];
+                if (beta != 0.0) v += beta * (*p);
+                *p = v;
+            }
+}
+
+template <bool BT>
+static void launch_gemm(hipStream_t s, const GemmArgs& g) {
+    const int Mmax = g.M > g.M_last ? g.M : g.M_last;
+    dim3 grid((g.N + 127) / 128, (Mmax + 127) / 128, g.nbatch);
+    constexpr size_t lds = (size_t)(128 * GA_S + (BT ? 128 * GA_S : 32 * GB_S)) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<BT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_gemm<BT>, grid, dim3(256), lds, s, g);
+}
+
+// =====================================================================================
+// Blocked right-looking Cholesky (lower), NB = 64 panels:
+//   diag block (LDS, + inverse)  ->  panel  L21 = A21 * inv(L11)^T  (MFMA GEMM, in place)
+//   ->  trailing  A22 -= L21 L21^T  (MFMA GEMM on the block lower triangle).
+// =====================================================================================
+void launch_potrf(hipStream_t s, double* K, double* W, int NP, int* info) {
+    const int nb = NP / NB;
+    constexpr size_t diag_lds = (size_t)(2 * NB * DS + 2 * NB) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_diag), hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_lds);
+        attr_set = true;
+    }
+    for (int kb = 0; kb < nb; ++kb) {
+        hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), diag_lds, s, K, W, NP, kb, info);
+        const int r0 = (kb + 1) * NB;
+        const int rem = NP - r0;
+        if (rem <= 0) break;
+        GemmArgs p{};
+        p.A = K + (size_t)r0 * NP + kb * NB; p.lda = NP; p.sA = 0;
+        p.B = W + (size_t)kb * NB * NP + kb * NB; p.ldb = NP; p.sB = 0;   // inv(L11) stored [n][k]
+        p.C = K + (size_t)r0 * NP + kb * NB; p.ldc = NP; p.sC = 0;       // in place: each tile reads its rows before writing
+        p.M = p.M_last = rem; p.N = NB; p.K = p.K_last = NB; p.nbatch = 1;
+        p.alpha = 1.0; p.beta = 0.0;
+        launch_gemm<true>(s, p);
+        GemmArgs u{};
+        u.A = K + (size_t)r0 * NP + kb * NB; u.lda = NP;
+        u.B = u.A; u.ldb = NP;
+        u.C = K + (size_t)r0 * NP + r0; u.ldc = NP;
+        u.M = u.M_last = rem; u.N = rem; u.K = u.K_last = NB; u.nbatch = 1;
+        u.alpha = -1.0; u.beta = 1.0; u.lower_only = 1;
+        launch_gemm<true>(s, u);
+    }
+}
+
+// =====================================================================================
+// W = L^-1 by recursive doubling.  The diagonal NB blocks of W already hold inv(L_kk).
+// Level s (s = NB, 2NB, ...): for each pair of adjacent s-blocks
+//     T   = L21 * W11          (W11 lower triangular: k >= j0)
+//     W21 = -W22 * T           (W22 lower triangular: k <  i0 + 128)
+// T lives in `scratch` (>= NP*NP/4 doubles; the not-yet-written Wf buffer is used).
+// =====================================================================================
+void launch_trinv(hipStream_t s, const double* L, double* W, int NP, double* scratch) {
+    for (long sz = NB; sz < NP; sz *= 2) {
+        const int npairs = (int)((NP + 2 * sz - 1) / (2 * sz));
+        // last pair: rows available for the second block
+        const long r0_last = (long)(npairs - 1) * 2 * sz;
+        long m_last = NP - r0_last - sz;
+        int nb = npairs;
+        if (m_last <= 0) { nb = npairs - 1; m_last = sz; }
+        if (nb <= 0) continue;
+        if (m_last > sz) m_last = sz;
+        const long pair_stride = 2 * sz * (long)NP + 2 * sz;
+        GemmArgs a{};
+        a.A = L + sz * (long)NP; a.lda = NP; a.sA = pair_stride;            // L21
+        a.B = W; a.ldb = NP; a.sB = pair_stride;                            // W11
+        a.C = scratch; a.ldc = sz; a.sC = sz * sz;                          // T
+        a.M = (int)sz; a.M_last = (int)m_last; a.N = (int)sz; a.K = a.K_last = (int)sz; a.nbatch = nb;
+        a.alpha = 1.0; a.beta = 0.0; a.b_lower = 1;
+        launch_gemm<false>(s, a);
+        GemmArgs c{};
+        c.A = W + sz * (long)NP + sz; c.lda = NP; c.sA = pair_stride;       // W22
+        c.B = scratch; c.ldb = sz; c.sB = sz * sz;                          // T
+        c.C = W + sz * (long)NP; c.ldc = NP; c.sC = pair_stride;            // W21
+        c.M = (int)sz; c.M_last = (int)m_last; c.N = (int)sz; c.K = (int)sz; c.K_last = (int)m_last; c.nbatch = nb;
+        c.alpha = -1.0; c.beta = 0.0; c.a_lower = 1;
+        launch_gemm<false>(s, c);
+    }
+}
+
+// =====================================================================================
+// alpha = K^-1 Y = W^T (W Y).   Y4 / tmp4 / A4 are [NP][4] (up to 4 outputs per pass).
+// fwd: one wave per row (coalesced row of W).  bwd: one workgroup per 64 columns, lanes on
+// columns (coalesced 512-B row segments), the 4 waves split the rows and reduce through LDS.
+// =====================================================================================
+__global__ __launch_bounds__(256) void k_alpha_fwd(const double* __restrict__ W, const double* __restrict__ Y4, int NP,
+                                                   double* __restrict__ T4) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= NP) return;
+    const double* wrow = W + (size_t)i * NP;
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    for (int j = lane; j <= i; j += 64) {
+        const double wv = wrow[j];
+        const d4 y = *reinterpret_cast<const d4*>(Y4 + (size_t)j * 4);
+        s0 += wv * y[0]; s1 += wv * y[1]; s2 += wv * y[2]; s3 += wv * y[3];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); s3 += __shfl_xor(s3, o);
+    }
+    if (lane == 0) *reinterpret_cast<d4*>(T4 + (size_t)i * 4) = d4{s0, s1, s2, s3};
+}
+
+__global__ __launch_bounds__(256) void k_alpha_bwd(const double* __restrict__ W, const double* __restrict__ T4, int N, int NP,
+                                                   double* __restrict__ A4) {
+    __shared__ double red[4][64][4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int j0 = blockIdx.x * 64;
+    const int j = j0 + lane;
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    for (int i = j0 + w; i < NP; i += 4) {
+        const double wv = W[(size_t)i * NP + j];        // zero above the diagonal
+        const d4 tv = *reinterpret_cast<const d4*>(T4 + (size_t)i * 4);
+        s0 += wv * tv[0]; s1 += wv * tv[1]; s2 += wv * tv[2]; s3 += wv * tv[3];
+    }
+    red[w][lane][0] = s0; red[w][lane][1] = s1; red[w][lane][2] = s2; red[w][lane][3] = s3;
+    __syncthreads();
+    if (w == 0) {
+        d4 r;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) r[o] = red[0][lane][o] + red[1][lane][o] + red[2][lane][o] + red[3][lane][o];
+        if (j >= N) r = d4{0, 0, 0, 0};
+        *reinterpret_cast<d4*>(A4 + (size_t)j * 4) = r;
+    }
+}
+
+void launch_alpha(hipStream_t s, const double* W, const double* Y4, int N, int NP, double* tmp4, double* A4) {
+    hipLaunchKernelGGL(k_alpha_fwd, dim3(NP / 4), dim3(256), 0, s, W, Y4, NP, tmp4);
+    hipLaunchKernelGGL(k_alpha_bwd, dim3(NP / 64), dim3(256), 0, s, W, tmp4, N, NP, A4);
+}
+
+// =====================================================================================
+// Pack W (row-major, lower) into the fragment-ordered tile stream Wf.
+// Tile (ib, kb), kb <= ib, index ib(ib+1)/2 + kb, WT x WT doubles each, laid out
+//   [k4 = 0..WT/4)[q = 0..WT/32)[lane = 0..64)[p = 0..2)
+// holding W[ib*WT + 16*(2q+p) + (lane&15)][kb*WT + 4*k4 + (lane>>4)]  — i.e. the A operand
+// of v_mfma_f64_16x16x4_f64 for row tiles 2q, 2q+1, 16 B per lane, 1 KiB per wave load.
+// Rows/cols >= N (padding) are zeroed so padded sources never reach a variance.
+// =====================================================================================
+size_t wf_doubles(int NP) {
+    const size_t nb = NP / WT;
+    return nb * (nb + 1) / 2 * WT_TILE_DOUBLES + WT_STEP_DOUBLES;   // + one k4-step of prefetch overrun
+}
+
+constexpr int PK_S = WT + 1;
+
+__global__ __launch_bounds__(256) void k_pack_w(const double* __restrict__ W, int N, int NP, double* __restrict__ Wf) {
+    extern __shared__ __attribute__((aligned(16))) double tile[];   // [WT][PK_S]
+    const int ib = blockIdx.y, kb = blockIdx.x;
+    if (kb > ib) return;
+    const int t = threadIdx.x;
+    for (int e = t; e < WT * WT; e += 256) {
+        const int r = e / WT, c = e % WT;
+        const int gr = ib * WT + r, gc = kb * WT + c;
+        double v = 0.0;
+        if (gr < N && gc < N && gc <= gr) v = W[(size_t)gr * NP + gc];
+        tile[r * PK_S + c] = v;
+    }
+    __syncthreads();
+    double* out = Wf + ((size_t)ib * (ib + 1) / 2 + kb) * WT_TILE_DOUBLES;
+    constexpr int NQ = WT / 32;
+    for (int e = t; e < WT_K4 * NQ * 64; e += 256) {
+        const int lane = e & 63, q = (e >> 6) % NQ, k4 = e / (64 * NQ);
+        const int lc = lane & 15, lk = lane >> 4;
+        const int col = 4 * k4 + lk;
+        const double v0 = tile[(16 * (2 * q) + lc) * PK_S + col];
+        const double v1 = tile[(16 * (2 * q + 1) + lc) * PK_S + col];
+        *reinterpret_cast<d2*>(out + (size_t)e * 2) = d2{v0, v1};
+    }
+}
+
+void launch_pack_w(hipStream_t s, const double* W, int N, int NP, double* Wf) {
+    const int nb = NP / WT;
+    const size_t lds = (size_t)WT * PK_S * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_pack_w), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_pack_w, dim3(nb, nb), dim3(256), lds, s, W, N, NP, Wf);
+    hipMemsetAsync(Wf + (wf_doubles(NP) - WT_STEP_DOUBLES), 0, WT_STEP_DOUBLES * sizeof(double), s);
+}
+
+// sum(log(diag(L))) over the first N rows (LML, sklearn/_gpr.py:603).  One workgroup.
+__global__ __launch_bounds__(256) void k_logdet(const double* __restrict__ K, int N, int NP, double* __restrict__ out) {
+    __shared__ double red[256];
+    double s = 0;
+    for (int i = threadIdx.x; i < N; i += 256) s += log(K[(size_t)i * NP + i]);
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = red[0];
+}
+
+void launch_logdet(hipStream_t s, const double* K, int N, int NP, double* out) {
+    hipLaunchKernelGGL(k_logdet, dim3(1), dim3(256), 0, s, K, N, NP, out);
+}
+
+}  // namespace gpt

@@ -1,0 +1,173 @@
+"""GaussianProcess — host-side mirror of the reference regressor
+(policy_transportation/models/gaussian_process.py:16-126) running on an MI355X through
+libgpt_hip.  Same constructor, methods, shapes and quirks; the numerics (Gram, Cholesky,
+alpha, posterior mean / variance / Jacobian / Jacobian variance / d var/dx) are HIP kernels.
+scikit-learn kernel objects are accepted as hyper-parameter containers only."""
+from __future__ import annotations
+
+import copy
+
+import numpy as np
+
+from . import _lib
+
+_PARAM_C = "k1__k1__constant_value"
+_PARAM_LS = "k1__k2__length_scale"
+_PARAM_NOISE = "k2__noise_level"
+
+
+def kernel_hyperparameters(kernel):
+    """(constant_value, length_scale array, noise_level) of a `ConstantKernel * RBF + WhiteKernel`
+    object — the parameter names the reference hard-codes (gaussian_process.py:39-41, 49)."""
+    try:
+        p = kernel.get_params()
+        c, ls, noise = p[_PARAM_C], p[_PARAM_LS], p[_PARAM_NOISE]
+    except (AttributeError, KeyError) as e:
+        raise ValueError("kernel must be ConstantKernel * RBF + WhiteKernel (as the reference's parameter "
+                         "names k1__k1__constant_value / k1__k2__length_scale / k2__noise_level require)") from e
+    stationary = type(p.get("k1__k2", None)).__name__
+    if stationary != "RBF":
+        raise NotImplementedError(f"only the RBF kernel runs on the GPU path, got {stationary}")
+    return float(c), np.atleast_1d(np.asarray(ls, dtype=np.float64)), float(noise)
+
+
+class _FittedView:
+    """Stands in for the reference's `self.gp` (the sklearn estimator): the fitted attributes
+    outside callers read, fetched from the device on first access."""
+
+    def __init__(self, owner):
+        self._o = owner
+        self._L = None
+        self._alpha_ = None
+        self.alpha = owner.alpha
+        self.kernel = owner._kernel_in
+        self.kernel_ = None
+        self.X_train_ = None
+        self.y_train_ = None
+        self.log_marginal_likelihood_value_ = None
+
+    @property
+    def alpha_(self):
+        if self._alpha_ is None:
+            self._alpha_ = self._o._handle.export(want_L=False)[1]
+        return self._alpha_
+
+    @property
+    def L_(self):
+        if self._L is None:
+            self._L = self._o._handle.export(want_alpha=False)[0]
+        return self._L
+
+
+class GaussianProcess:
+    def __init__(self, kernel, alpha=1e-10, optimizer="fmin_l_bfgs_b", n_restarts_optimizer=5, n_targets=None,
+                 device=0, verbose=True):
+        self._kernel_in = kernel
+        self.kernel = kernel
+        self.alpha = alpha
+        self.optimizer = optimizer
+        self.n_restarts_optimizer = n_restarts_optimizer if optimizer is not None else 0
+        self.n_targets = n_targets
+        self.device = device
+        self.verbose = verbose
+        self._handle = None
+        self._K_inv = None
+        self.gp = _FittedView(self)
+
+    # ------------------------------------------------------------------ fit
+    def fit(self, X, Y):
+        X = np.asarray(X, dtype=np.float64)
+        Y = np.asarray(Y, dtype=np.float64)
+        if Y.ndim == 1:
+            Y = Y[:, None]
+        self.X = X
+        self.Y = Y
+        self.n_features = np.shape(X)[1]
+        self.n_samples = np.shape(X)[0]          # pre-filter count, as the reference (:29)
+        self.n_outputs = np.shape(Y)[1]
+        mask = np.isnan(Y).any(axis=1)           # (:33-35)
+        self.X = X[~mask]
+        self.Y = Y[~mask]
+        if self.n_targets is not None and self.n_outputs != self.n_targets:   # sklearn/_gpr.py:265-269
+            raise ValueError(f"The number of targets seen in `y` is different from the parameter `n_targets`. "
+                             f"Got {self.n_outputs} != {self.n_targets}.")
+        c, ls, noise = kernel_hyperparameters(self._kernel_in)
+        if self.optimizer is not None:
+            from .hyperopt import optimize_hyperparameters
+            c, ls, noise, lml = optimize_hyperparameters(self, c, ls, noise)
+        if self._handle is None:
+            self._handle = _lib.Handle(self.device)
+        self._handle.fit(self.X, self.Y, ls, c, noise, self.alpha)
+        self._K_inv = None
+        # fitted kernel object with the reference's attribute protocol (:38-41)
+        fitted = copy.deepcopy(self._kernel_in)
+        keep_array = np.iterable(self._kernel_in.get_params()[_PARAM_LS])
+        fitted.set_params(**{_PARAM_C: c, _PARAM_LS: (ls.copy() if keep_array else float(ls[0])), _PARAM_NOISE: noise})
+        self.kernel = fitted
+        self.gp = _FittedView(self)
+        self.gp.kernel_ = fitted
+        self.gp.X_train_ = self.X
+        self.gp.y_train_ = self.Y
+        self.kernel_params_ = [fitted.get_params()[_PARAM_LS], fitted.get_params()["k1"]]
+        self.noise_var_ = self.alpha + noise
+        self.prior_var = c
+        self._c, self._ls, self._noise = c, ls, noise
+        if self.verbose:
+            print("lenghtscales", fitted.get_params()[_PARAM_LS])
+        return self
+
+    @property
+    def K_inv(self):
+        """(c*RBF + noise_var_*I)^-1 as the reference caches it (:42-43).  Only reference-internal
+        code reads it; here it is assembled lazily from the device factor W = L^-1 (K^-1 = W^T W)."""
+        if self._K_inv is None:
+            W = self._handle.export_inverse_factor()
+            self._K_inv = W.T @ W
+        return self._K_inv
+
+    def _require_fit(self):
+        if self._handle is None:
+            raise RuntimeError("GaussianProcess is not fitted")
+
+    # ------------------------------------------------------------------ predict
+    def predict(self, x, return_std=False, return_cov=False):
+        """(:46-55)  mean (M,O); with return_std also `std - sqrt(noise_level)` tiled over outputs."""
+        self._require_fit()
+        if return_std and return_cov:
+            raise RuntimeError("At most one of return_std or return_cov can be requested.")
+        if return_cov:
+            raise NotImplementedError("return_cov (M x M posterior covariance) is not on the GPU path yet")
+        out = self._handle.predict_all(x, mean=True, var=bool(return_std))
+        mean = out["mean"]
+        if self.n_outputs == 1:
+            mean = mean[:, 0]                       # sklearn squeezes single-target output (_gpr.py:449-451)
+        if not return_std:
+            return mean
+        std = np.sqrt(out["var"])
+        if self.n_outputs > 1:
+            std = np.repeat(std[:, None], self.n_outputs, axis=1)   # _gpr.py:488
+        return mean, std - np.sqrt(self._noise)     # reference quirk (:49)
+
+    def samples(self, x):
+        raise NotImplementedError("samples() (posterior draws over an M x M covariance) is not on the GPU path yet")
+
+    # ------------------------------------------------------------------ derivatives
+    def derivative(self, x, return_var=False):
+        """(:63-102)  J (M,O,D) = d mean_o / d x_d; with return_var also its variance, tiled over outputs."""
+        self._require_fit()
+        out = self._handle.predict_all(x, J=True, Jvar=bool(return_var))
+        if not return_var:
+            return out["J"]
+        Sigma = np.repeat(out["Jvar"][:, None, :], self.n_outputs, axis=1)
+        return out["J"], Sigma
+
+    def derivative_of_variance(self, x):
+        """(:104-126)  (D, M) array of d var / d x_d."""
+        self._require_fit()
+        return self._handle.predict_all(x, dvar=True)["dvar"]
+
+    # ------------------------------------------------------------------ fused metric path
+    def posterior(self, x, jacobian_variance=False):
+        """One call for mean (M,O), raw variance (M,), Jacobian (M,O,D) [and Jacobian variance (M,D)]."""
+        self._require_fit()
+        return self._handle.predict_all(x, mean=True, var=True, J=True, Jvar=bool(jacobian_variance))
