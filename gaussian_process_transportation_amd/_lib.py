@@ -3,7 +3,9 @@ GPU is missing, every compute entry point raises."""
 from __future__ import annotations
 
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 import numpy as np
 
@@ -39,6 +41,8 @@ SIGNATURES = {
     "gpt_factor_commit": (C.c_int, [_vp]),
     "gpt_info": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_i64)]),
     "gpt_fit_timings": (C.c_int, [_vp, _dp, C.c_int]),
+    "gpt_set_profiling": (C.c_int, [_vp, C.c_int]),
+    "gpt_predict_timings": (C.c_int, [_vp, _dp]),
 }
 
 _lib = None
@@ -48,11 +52,33 @@ class GptError(RuntimeError):
     pass
 
 
+def _preload_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so with the same SONAME as /opt/rocm's.  The
+    first copy loaded serves the whole process, and torch cannot initialise on a foreign copy
+    ("No HIP GPUs are available").  When torch is installed but not yet imported, load ITS runtime
+    first so that libgpt_hip.so and a later `import torch` share one HIP runtime in either order."""
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """Load libgpt_hip.so (built by `__graft_entry__.build()` / csrc/Makefile).  Fails loudly."""
     global _lib
     if _lib is not None:
         return _lib
+    _preload_hip_runtime()
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
@@ -183,6 +209,14 @@ class Handle:
         check(self.lib.gpt_predict_all_dev(self._h, _vp(xq_ptr), int(M), _vp(mean_ptr or None), _vp(var_ptr or None),
                                            _vp(J_ptr or None), _vp(Jvar_ptr or None), _vp(dvar_ptr or None)),
               "gpt_predict_all_dev")
+
+    def set_profiling(self, enable=True):
+        check(self.lib.gpt_set_profiling(self._h, int(bool(enable))), "gpt_set_profiling")
+
+    def predict_timings(self):
+        t = np.zeros(2)
+        check(self.lib.gpt_predict_timings(self._h, dptr(t)), "gpt_predict_timings")
+        return {"mean_jac_ms": float(t[0]), "var_ms": float(t[1])}
 
     def set_stream(self, stream_ptr):
         check(self.lib.gpt_set_stream(self._h, _vp(stream_ptr or None)), "gpt_set_stream")

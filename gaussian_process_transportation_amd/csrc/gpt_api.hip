@@ -75,6 +75,9 @@ struct gpt_handle {
     int sD = 0, sO = 0;
     double fit_ms[6] = {0, 0, 0, 0, 0, 0};
     hipEvent_t ev[7] = {};
+    // per-kernel timing of the last predict (gpt_set_profiling)
+    bool profiling = false, pred_mj = false, pred_var = false;
+    hipEvent_t pev[4] = {};
 
     double* dXs() const { return blob + lay.off_xs; }
     double* dA4() const { return blob + lay.off_a4; }
@@ -179,6 +182,10 @@ int gpt_create(gpt_handle** out, int device) {
         e = hipEventCreate(&ev);
         if (e != hipSuccess) { delete h; return fail(GPT_E_HIP, std::string("hipEventCreate: ") + hipGetErrorString(e)); }
     }
+    for (auto& ev : h->pev) {
+        e = hipEventCreate(&ev);
+        if (e != hipSuccess) { delete h; return fail(GPT_E_HIP, std::string("hipEventCreate: ") + hipGetErrorString(e)); }
+    }
     *out = h;
     return GPT_OK;
 }
@@ -191,6 +198,7 @@ void gpt_destroy(gpt_handle* h) {
     free_workspace(h);
     if (h->blob) (void)hipFree(h->blob);
     for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
+    for (auto& ev : h->pev) if (ev) (void)hipEventDestroy(ev);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
 }
@@ -291,9 +299,20 @@ int gpt_predict_all_dev(gpt_handle* h, const double* Xq, int64_t M, double* mean
     if (M == 0) return GPT_OK;
     if (int rc = set_device(h)) return rc;
     hipStream_t s = h->stream;
-    if (mean || J) launch_mean_jac(s, h->p, h->dXs(), h->dA4(), Xq, M, mean, J);
-    if (Jvar || dvar) launch_var(s, h->p, h->dXs(), h->dWf(), Xq, M, 4, var, Jvar, dvar);
-    else if (var) launch_var(s, h->p, h->dXs(), h->dWf(), Xq, M, 1, var, nullptr, nullptr);
+    const bool prof = h->profiling;
+    h->pred_mj = (mean || J);
+    h->pred_var = (var || Jvar || dvar);
+    if (h->pred_mj) {
+        if (prof) HIPCHK(hipEventRecord(h->pev[0], s));
+        launch_mean_jac(s, h->p, h->dXs(), h->dA4(), Xq, M, mean, J);
+        if (prof) HIPCHK(hipEventRecord(h->pev[1], s));
+    }
+    if (h->pred_var) {
+        if (prof) HIPCHK(hipEventRecord(h->pev[2], s));
+        if (Jvar || dvar) launch_var(s, h->p, h->dXs(), h->dWf(), Xq, M, 4, var, Jvar, dvar);
+        else launch_var(s, h->p, h->dXs(), h->dWf(), Xq, M, 1, var, nullptr, nullptr);
+        if (prof) HIPCHK(hipEventRecord(h->pev[3], s));
+    }
     HIPCHK(hipGetLastError());
     return GPT_OK;
 }
@@ -438,6 +457,31 @@ int gpt_info(gpt_handle* h, int64_t* N, int* D, int* O, int64_t* N_padded) {
     if (D) *D = h->p.D;
     if (O) *O = h->p.O;
     if (N_padded) *N_padded = h->p.NP;
+    return GPT_OK;
+}
+
+int gpt_set_profiling(gpt_handle* h, int enable) {
+    if (!h) return fail(GPT_E_ARG, "gpt_set_profiling: NULL handle");
+    h->profiling = enable != 0;
+    return GPT_OK;
+}
+
+int gpt_predict_timings(gpt_handle* h, double* ms_out) {
+    if (!h || !ms_out) return fail(GPT_E_ARG, "gpt_predict_timings: NULL argument");
+    if (!h->profiling) return fail(GPT_E_STATE, "gpt_predict_timings: profiling is off (gpt_set_profiling)");
+    if (int rc = set_device(h)) return rc;
+    ms_out[0] = ms_out[1] = 0.0;
+    float ms = 0;
+    if (h->pred_mj) {
+        HIPCHK(hipEventSynchronize(h->pev[1]));
+        HIPCHK(hipEventElapsedTime(&ms, h->pev[0], h->pev[1]));
+        ms_out[0] = ms;
+    }
+    if (h->pred_var) {
+        HIPCHK(hipEventSynchronize(h->pev[3]));
+        HIPCHK(hipEventElapsedTime(&ms, h->pev[2], h->pev[3]));
+        ms_out[1] = ms;
+    }
     return GPT_OK;
 }
 

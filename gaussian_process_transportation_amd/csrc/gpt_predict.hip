@@ -16,6 +16,7 @@
 //               squared and summed per column when an i-block is finished, so V = W K*^T never
 //               touches memory.
 #include "gpt_common.h"
+#include <cstdlib>
 
 namespace gpt {
 
@@ -111,10 +112,31 @@ void launch_mean_jac(hipStream_t s, const KernelParams& p, const double* Xs, con
 // Variance kernel.  512 threads = 8 waves (2 per SIMD); the workgroup owns 256 columns, each wave
 // 32 of them (2 MFMA column tiles) against all WT=128 rows of the current i-block (8 row tiles).
 // NCOMP = 1: one column per query (k*).  NCOMP = 4: four columns per query (k*, dk_0, dk_1, dk_2).
+//
+// SCHED selects how the B-operand generation (fp64 exp on the VALU) is overlapped with the MFMAs:
+//   0  generate b for step k, then its 16 MFMAs (two phases per step)
+//   1  as 0, with s_setprio 1 around the MFMA phase so the two waves of a SIMD alternate phases
+//      instead of drifting into lockstep (both in the VALU phase = idle matrix pipe)
+//   2  software-pipelined: b for step k+1 is generated while the MFMAs of step k issue; the two
+//      instruction streams are interleaved with sched_group_barrier (1 MFMA : 5 VALU)
+//   3  as 2 without the explicit interleave (compiler order) but with s_setprio around the MFMAs
 // ------------------------------------------------------------------------------------------
 constexpr int VAR_COLS = 256;
 
-template <int NCOMP, bool CROSS>
+template <int NCOMP>
+__device__ __forceinline__ void make_b(const double x0, const double x1, const double x2, const double (&q)[2][3],
+                                       const double (&cb)[2], const double (&cd)[2][3], const double c,
+                                       double (&b)[2]) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const double d0 = x0 - q[t][0], d1 = x1 - q[t][1], d2_ = x2 - q[t][2];
+        const double kv = c * exp(-0.5 * (d0 * d0 + d1 * d1 + d2_ * d2_));
+        if (NCOMP == 1) b[t] = kv;
+        else b[t] = kv * (cb[t] + cd[t][0] * d0 + cd[t][1] * d1 + cd[t][2] * d2_);
+    }
+}
+
+template <int NCOMP, bool CROSS, int SCHED>
 __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, const double* __restrict__ Xs,
                                                 const double* __restrict__ Wf, const double* __restrict__ Xq,
                                                 int64_t M, double* __restrict__ var, double* __restrict__ Jvar,
@@ -146,6 +168,7 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, const double* __
     constexpr int NQ = WT_RT / 2;                  // 16-byte fragment pairs per k4-step (4)
     const d2* wp = reinterpret_cast<const d2*>(Wf) + lane;   // stream pointer (d2 units)
     constexpr size_t STEP_D2 = WT_STEP_DOUBLES / 2;          // d2 per k4-step (256)
+    constexpr bool PIPE_B = (SCHED >= 2);
 
     // prologue of the software pipeline: fragments + source coords of the first k4-step
     d2 a_nxt[NQ];
@@ -155,6 +178,12 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, const double* __
     double xs_nxt[3];
     {
         const double* xp = Xs + (size_t)lk * 4;
+        xs_nxt[0] = xp[0]; xs_nxt[1] = xp[1]; xs_nxt[2] = xp[2];
+    }
+    double b_nxt[2] = {0.0, 0.0};
+    if (PIPE_B) {   // b of step 0 now, coords of step 1 in flight
+        make_b<NCOMP>(xs_nxt[0], xs_nxt[1], xs_nxt[2], q, cb, cd, c, b_nxt);
+        const double* xp = Xs + (size_t)(4 + lk) * 4;
         xs_nxt[0] = xp[0]; xs_nxt[1] = xp[1]; xs_nxt[2] = xp[2];
     }
 
@@ -174,24 +203,35 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, const double* __
             for (int u = 0; u < NQ; ++u) a_nxt[u] = wp[u * 64];
             wp += STEP_D2;
             {
-                const int jn = (k4 + 1 < nk4) ? ((k4 + 1) * 4 + lk) : lk;
-                const double* xp = Xs + (size_t)jn * 4;
+                // coords wanted next: step k4+1 (two-phase) or k4+2 (pipelined), wrapping into the
+                // next i-block, whose k-sweep restarts at source 0
+                const int ahead = PIPE_B ? 2 : 1;
+                const int kn = (k4 + ahead < nk4) ? (k4 + ahead) : (k4 + ahead - nk4);
+                const double* xp = Xs + (size_t)(kn * 4 + lk) * 4;
                 xs_nxt[0] = xp[0]; xs_nxt[1] = xp[1]; xs_nxt[2] = xp[2];
             }
             double b[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const double d0 = x0 - q[t][0], d1 = x1 - q[t][1], d2_ = x2 - q[t][2];
-                const double kv = c * exp(-0.5 * (d0 * d0 + d1 * d1 + d2_ * d2_));
-                if (NCOMP == 1) b[t] = kv;
-                else b[t] = kv * (cb[t] + cd[t][0] * d0 + cd[t][1] * d1 + cd[t][2] * d2_);
+            if (PIPE_B) {
+                b[0] = b_nxt[0]; b[1] = b_nxt[1];
+                make_b<NCOMP>(x0, x1, x2, q, cb, cd, c, b_nxt);     // for step k4+1, independent of the MFMAs below
+            } else {
+                make_b<NCOMP>(x0, x1, x2, q, cb, cd, c, b);
             }
+            if (SCHED == 1 || SCHED == 3) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int u = 0; u < NQ; ++u) {
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     acc[2 * u][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[u][0], b[t], acc[2 * u][t], 0, 0, 0);
                     acc[2 * u + 1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[u][1], b[t], acc[2 * u + 1][t], 0, 0, 0);
+                }
+            }
+            if (SCHED == 1 || SCHED == 3) __builtin_amdgcn_s_setprio(0);
+            if (SCHED == 2) {
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);   // 5 VALU
                 }
             }
         }
@@ -231,17 +271,38 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, const double* __
     }
 }
 
+static int var_sched() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("GPT_VAR_SCHED");
+        v = e ? atoi(e) : 1;
+        if (v < 0 || v > 3) v = 1;
+    }
+    return v;
+}
+
+template <int SCHED>
+static void launch_var_s(hipStream_t s, const KernelParams& p, const double* Xs, const double* Wf,
+                         const double* Xq, int64_t M, int ncomp, double* var, double* Jvar, double* dvar, unsigned blocks) {
+    if (ncomp == 1) {
+        hipLaunchKernelGGL((k_var<1, false, SCHED>), dim3(blocks), dim3(512), 0, s, p, Xs, Wf, Xq, M, var, Jvar, dvar);
+    } else if (dvar) {
+        hipLaunchKernelGGL((k_var<4, true, SCHED>), dim3(blocks), dim3(512), 0, s, p, Xs, Wf, Xq, M, var, Jvar, dvar);
+    } else {
+        hipLaunchKernelGGL((k_var<4, false, SCHED>), dim3(blocks), dim3(512), 0, s, p, Xs, Wf, Xq, M, var, Jvar, dvar);
+    }
+}
+
 void launch_var(hipStream_t s, const KernelParams& p, const double* Xs, const double* Wf,
                 const double* Xq, int64_t M, int ncomp, double* var, double* Jvar, double* dvar) {
     if (M <= 0) return;
     const int64_t cols = M * ncomp;
     const unsigned blocks = (unsigned)((cols + VAR_COLS - 1) / VAR_COLS);
-    if (ncomp == 1) {
-        hipLaunchKernelGGL((k_var<1, false>), dim3(blocks), dim3(512), 0, s, p, Xs, Wf, Xq, M, var, Jvar, dvar);
-    } else if (dvar) {
-        hipLaunchKernelGGL((k_var<4, true>), dim3(blocks), dim3(512), 0, s, p, Xs, Wf, Xq, M, var, Jvar, dvar);
-    } else {
-        hipLaunchKernelGGL((k_var<4, false>), dim3(blocks), dim3(512), 0, s, p, Xs, Wf, Xq, M, var, Jvar, dvar);
+    switch (var_sched()) {
+        case 0: launch_var_s<0>(s, p, Xs, Wf, Xq, M, ncomp, var, Jvar, dvar, blocks); break;
+        case 2: launch_var_s<2>(s, p, Xs, Wf, Xq, M, ncomp, var, Jvar, dvar, blocks); break;
+        case 3: launch_var_s<3>(s, p, Xs, Wf, Xq, M, ncomp, var, Jvar, dvar, blocks); break;
+        default: launch_var_s<1>(s, p, Xs, Wf, Xq, M, ncomp, var, Jvar, dvar, blocks); break;
     }
 }
 

@@ -110,6 +110,13 @@ int gpt_info(gpt_handle* h, int64_t* N, int* D, int* O, int64_t* N_padded);
  * [0] total [1] gram [2] cholesky [3] triangular inverse [4] alpha [5] pack.  n <= 6. */
 int gpt_fit_timings(gpt_handle* h, double* ms_out, int n);
 
+/* Per-kernel device times of the last gpt_predict_all_dev call.  With profiling enabled the call
+ * records hipEvents around each kernel on the handle's stream (no host synchronisation);
+ * gpt_predict_timings waits for them and returns ms_out[0] = mean+Jacobian contraction kernel,
+ * ms_out[1] = variance (MFMA) kernel; 0 for a kernel that was not launched. */
+int gpt_set_profiling(gpt_handle* h, int enable);
+int gpt_predict_timings(gpt_handle* h, double* ms_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,297 @@
+"""Parity of the HIP path (through the C ABI and the Python mirror of the reference API) against
+golden vectors captured from the reference and against the CPU oracle.  Needs an MI355X.
+
+Tolerance: north_star's 1e-5 relative (fp64), applied as max-norm relative error per output array
+plus elementwise rtol/atol (tests/conftest.py:assert_parity)."""
+import numpy as np
+import pytest
+
+from tests.conftest import assert_parity, load_golden
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+
+
+def sk_kernel(c, ls, noise):
+    from sklearn.gaussian_process.kernels import RBF, WhiteKernel, ConstantKernel as C
+    return C(float(c)) * RBF(length_scale=np.asarray(ls, dtype=float).tolist() if np.size(ls) > 1 else [float(np.ravel(ls)[0])]) \
+        + WhiteKernel(float(noise))
+
+
+def fitted_gp(g):
+    from gaussian_process_transportation_amd import GaussianProcess
+    gp = GaussianProcess(kernel=sk_kernel(g["constant_value"], g["length_scale"], g["noise_level"]),
+                         alpha=float(g["alpha"]), optimizer=None, verbose=False)
+    gp.fit(g["X"], g["Y"])
+    return gp
+
+
+SYN = ["synthetic_3d_N64", "synthetic_3d_N64_iso", "synthetic_3d_N64_nan", "synthetic_3d_N256", "synthetic_3d_N1024"]
+
+
+@pytest.mark.parametrize("name", SYN)
+def test_golden_fit(name):
+    g = load_golden(name)
+    gp = fitted_gp(g)
+    assert gp.n_samples == int(g["n_samples"])
+    assert gp.X.shape[0] == g["alpha_"].shape[0]            # NaN rows dropped
+    assert_parity(gp.gp.alpha_, g["alpha_"], RTOL, "alpha_")
+    L = gp.gp.L_
+    assert np.all(np.triu(L, 1) == 0.0)
+    if "L_" in g:
+        assert_parity(L, g["L_"], RTOL, "L_")
+    else:
+        assert_parity(np.diag(L), g["L_diag"], RTOL, "diag L")
+        assert_parity(L[:, 0], g["L_col0"], RTOL, "L[:,0]")
+        assert_parity(L[-1], g["L_lastrow"], RTOL, "L[-1]")
+    assert gp.noise_var_ == pytest.approx(float(g["noise_var_"]), rel=1e-15)
+    assert gp.prior_var == pytest.approx(float(g["prior_var"]), rel=1e-15)
+    if "lml_value" in g:
+        assert gp._handle.lml() == pytest.approx(float(g["lml_value"][0]), rel=1e-9)
+    # K_inv as the reference caches it
+    K = g["constant_value"] * np.exp(-0.5 * (((gp.X[:, None, :] - gp.X[None, :, :]) / g["length_scale"]) ** 2).sum(-1))
+    K[np.diag_indices_from(K)] += gp.noise_var_
+    assert_parity(gp.K_inv @ K, np.eye(len(K)), 1e-6, "K_inv K")
+
+
+@pytest.mark.parametrize("name", SYN)
+def test_golden_predict_and_derivatives(name):
+    g = load_golden(name)
+    gp = fitted_gp(g)
+    Xq = g["Xq"]
+    assert_parity(gp.predict(Xq), g["mean_only"], RTOL, "mean only")
+    m, s = gp.predict(Xq, return_std=True)
+    assert_parity(m, g["mean"], RTOL, "mean")
+    assert_parity(s, g["std"], RTOL, "std")
+    assert_parity(gp.derivative(Xq), g["J"], RTOL, "J (no var)")
+    J, Jv = gp.derivative(Xq, return_var=True)
+    assert_parity(J, g["J"], RTOL, "J")
+    assert_parity(Jv, g["Jvar"], RTOL, "Jvar")
+    assert_parity(gp.derivative_of_variance(Xq), g["dvar"], RTOL, "dvar")
+    post = gp.posterior(Xq, jacobian_variance=True)
+    assert_parity(post["mean"], g["mean"], RTOL, "fused mean")
+    assert_parity(np.sqrt(post["var"]) - np.sqrt(float(g["noise_level"])), g["std"][:, 0], RTOL, "fused std")
+    assert_parity(post["J"], g["J"], RTOL, "fused J")
+    assert_parity(post["Jvar"], g["Jvar"][:, 0, :], RTOL, "fused Jvar")
+
+
+def test_golden_n8192_spot_check():
+    """Config-3 size against the reference itself: 256 queries at N=8192 (fixture holds no X/Y: regenerated
+    from the documented seeds)."""
+    g = load_golden("synthetic_3d_N8192")
+    rng = np.random.default_rng(0)
+    X = rng.uniform(0, 1, (8192, 3))
+    Y = 0.05 * np.sin(4 * X) + 0.01 * rng.standard_normal((8192, 3))
+    g = dict(g, X=X, Y=Y)
+    gp = fitted_gp(g)
+    assert_parity(gp.gp.alpha_, g["alpha_"], RTOL, "alpha_")
+    L = gp.gp.L_
+    assert_parity(np.diag(L), g["L_diag"], RTOL, "diag L")
+    assert_parity(L[:, 0], g["L_col0"], RTOL, "L[:,0]")
+    assert_parity(L[-1], g["L_lastrow"], RTOL, "L[-1]")
+    del L
+    m, s = gp.predict(g["Xq"], return_std=True)
+    assert_parity(m, g["mean"], RTOL, "mean")
+    assert_parity(s, g["std"], RTOL, "std")
+    J, Jv = gp.derivative(g["Xq"], return_var=True)
+    assert_parity(J, g["J"], RTOL, "J")
+    assert_parity(Jv, g["Jvar"], RTOL, "Jvar")
+    assert_parity(gp.derivative_of_variance(g["Xq"]), g["dvar"], RTOL, "dvar")
+
+
+def _transport(g, do_scale=False):
+    from gaussian_process_transportation_amd import GaussianProcessTransportation
+    tr = GaussianProcessTransportation(kernel_transport=sk_kernel(g["constant_value"], g["length_scale"], g["noise_level"]),
+                                       optimizer=None, verbose=False)
+    tr.source_distribution = g["source"]
+    tr.target_distribution = g["target"]
+    tr.training_traj = g["demo"]
+    tr.training_delta = g["delta"]
+    tr.fit_transportation(do_scale=do_scale, do_rotation=True)
+    tr.apply_transportation()
+    return tr
+
+
+def test_letterS_transport_fixed_theta():
+    """Config 1 (2-D letter-S demo) with the hyper-parameters the reference's optimizer found."""
+    g = load_golden("letterS_2d")
+    tr = _transport(g)
+    assert_parity(tr.method.affine_transform.rotation_matrix, g["rotation"], 1e-12, "R")
+    assert_parity(tr.method.delta_map.gp.alpha_, g["alpha_"], RTOL, "alpha_")
+    assert_parity(tr.method.delta_map.gp.L_, g["L_"], RTOL, "L_")
+    assert_parity(tr.training_traj, g["traj"], RTOL, "traj")
+    assert_parity(tr.std, g["std"], RTOL, "std")
+    assert_parity(tr.training_delta, g["vel"], RTOL, "vel")
+    assert_parity(tr.var_vel_transported, g["var_vel"], RTOL, "var_vel")
+    assert tr.training_traj_old is g["demo"]
+    tr2 = _transport(g, do_scale=True)
+    assert float(tr2.method.affine_transform.scale) == pytest.approx(float(g["scale2"]), rel=1e-12)
+    assert_parity(tr2.training_traj, g["traj2"], RTOL, "traj2")
+    assert_parity(tr2.training_delta, g["vel2"], RTOL, "vel2")
+    assert_parity(tr2.var_vel_transported, g["var_vel2"], RTOL, "var_vel2")
+
+
+def test_surface3d_transport_fixed_theta():
+    """The reference's 3-D surface demo (N=2500 sources, 460-point demo) at its fitted theta."""
+    g = load_golden("surface_3d")
+    tr = _transport(g)
+    assert_parity(tr.method.delta_map.gp.alpha_, g["alpha_"], RTOL, "alpha_")
+    assert_parity(tr.training_traj, g["traj"], RTOL, "traj")
+    assert_parity(tr.std, g["std"], RTOL, "std")
+    assert_parity(tr.training_delta, g["vel"], RTOL, "vel")
+    assert_parity(tr.var_vel_transported, g["var_vel"], RTOL, "var_vel")
+
+
+@pytest.mark.parametrize("N,M,D,O,ls", [(1, 5, 3, 3, (0.1,)), (3, 1, 2, 2, (0.3, 0.2)), (63, 257, 3, 3, (0.1, 0.2, 0.3)),
+                                        (257, 300, 1, 5, (0.05,)), (700, 1031, 3, 1, (0.15,)), (1300, 513, 2, 6, (0.2, 0.1))])
+def test_ragged_shapes_vs_oracle(N, M, D, O, ls):
+    """Sizes off every tile boundary, D in 1..3, O from 1 to more than one alpha pass."""
+    from gaussian_process_transportation_amd import _lib
+    from oracle import gp_oracle as orc
+    rng = np.random.default_rng(N + M)
+    X = rng.uniform(0, 1, (N, D))
+    Y = 0.05 * np.sin(4 * X[:, :1] + np.arange(O)[None, :]) + 0.01 * rng.standard_normal((N, O))
+    Xq = rng.uniform(-0.1, 1.1, (M, D))
+    c, noise, jit = 0.1, 1e-4, 1e-10
+    h = _lib.Handle(0)
+    h.fit(X, Y, np.asarray(ls), c, noise, jit)
+    o = orc.GaussianProcessOracle(c, np.asarray(ls), noise, jit).fit(X, Y)
+    L, a = h.export()
+    assert_parity(L, o.L_, RTOL, "L")
+    assert_parity(a, o.alpha_, RTOL, "alpha")
+    out = h.predict_all(Xq, mean=True, var=True, J=True, Jvar=True, dvar=True)
+    mean, std = o.predict(Xq, return_std=True)
+    std = std if std.ndim == 1 else std[:, 0]
+    J, Jv = o.derivative(Xq, return_var=True)
+    assert_parity(out["mean"], np.reshape(mean, (M, O)), RTOL, "mean")
+    assert_parity(out["var"], (std + np.sqrt(noise)) ** 2, RTOL, "var")
+    assert_parity(out["J"], J, RTOL, "J")
+    assert_parity(out["Jvar"], Jv[:, 0, :], RTOL, "Jvar")
+    assert_parity(out["dvar"], o.derivative_of_variance(Xq), RTOL, "dvar")
+    assert_parity(h.predict_all(Xq, var=True)["var"], out["var"], 1e-12, "var (1-column kernel) vs var (4-column kernel)")
+    h.close()
+
+
+def test_empty_query_and_errors():
+    from gaussian_process_transportation_amd import _lib, GaussianProcess
+    h = _lib.Handle(0)
+    with pytest.raises(_lib.GptError):
+        h.predict_all(np.zeros((3, 3)), mean=True)                     # not fitted
+    X = np.random.default_rng(0).uniform(0, 1, (40, 3))
+    Y = np.sin(X)
+    h.fit(X, Y, np.array([0.2]), 1.0, 1e-3, 1e-10)
+    out = h.predict_all(np.zeros((0, 3)), mean=True, var=True, J=True)
+    assert out["mean"].shape == (0, 3) and out["var"].shape == (0,) and out["J"].shape == (0, 3, 3)
+    with pytest.raises(ValueError):
+        h.predict_all(np.zeros((4, 2)), mean=True)                     # wrong feature count
+    with pytest.raises(ValueError):
+        h.fit(X, Y, np.array([0.2, 0.1]), 1.0, 1e-3, 1e-10)            # n_ls not in {1, D}
+    with pytest.raises(ValueError):
+        h.fit(X, Y, np.array([-0.2]), 1.0, 1e-3, 1e-10)
+    # duplicated points with no noise and no jitter: not positive definite -> LinAlgError as sklearn
+    Xd = np.vstack([X, X])
+    with pytest.raises(np.linalg.LinAlgError):
+        h.fit(Xd, np.vstack([Y, Y]), np.array([0.2]), 1.0, 0.0, 0.0)
+    # a failed fit leaves the handle unfitted, a new fit recovers it
+    with pytest.raises(_lib.GptError):
+        h.predict_all(np.zeros((3, 3)), mean=True)
+    h.fit(X, Y, np.array([0.2]), 1.0, 1e-3, 1e-10)
+    assert np.all(np.isfinite(h.predict_all(X, mean=True)["mean"]))
+    h.close()
+    from sklearn.gaussian_process.kernels import RBF, Matern, WhiteKernel, ConstantKernel as C
+    with pytest.raises(ValueError):
+        GaussianProcess(kernel=C(1.0) * RBF(0.1) + WhiteKernel(1e-3), optimizer=None, n_targets=2, verbose=False).fit(X, Y)
+    with pytest.raises(NotImplementedError):
+        GaussianProcess(kernel=C(1.0) * Matern(0.1) + WhiteKernel(1e-3), optimizer=None, verbose=False).fit(X, Y)
+    with pytest.raises(ValueError):
+        GaussianProcess(kernel=RBF(0.1), optimizer=None, verbose=False).fit(X, Y)
+
+
+def test_single_target_shapes_follow_sklearn():
+    from gaussian_process_transportation_amd import GaussianProcess
+    from sklearn.gaussian_process.kernels import RBF, WhiteKernel, ConstantKernel as C
+    rng = np.random.default_rng(3)
+    X = rng.uniform(0, 1, (50, 2))
+    y = np.sin(3 * X[:, 0])
+    gp = GaussianProcess(kernel=C(1.0) * RBF([0.3, 0.3]) + WhiteKernel(1e-3), optimizer=None, verbose=False).fit(X, y)
+    m, s = gp.predict(X[:7], return_std=True)
+    assert m.shape == (7,) and s.shape == (7,)
+    assert gp.derivative(X[:7]).shape == (7, 1, 2)
+
+
+def test_full_size_properties():
+    """Config 3 size (N=8192, M=500k) through size-independent identities:
+    (a) K alpha = y  =>  mean(X_train) = y - noise_var * alpha;
+    (b) the Jacobian is the central finite difference of the mean;
+    (c) d var/dx is the central finite difference of the variance;
+    (d) the 1-column and 4-column variance kernels agree; variance within [0, c + noise]."""
+    from gaussian_process_transportation_amd import _lib
+    N, M, D = 8192, 500_000, 3
+    rng = np.random.default_rng(0)
+    X = rng.uniform(0, 1, (N, D))
+    Y = 0.05 * np.sin(4 * X) + 0.01 * rng.standard_normal((N, D))
+    Xq = np.random.default_rng(1).uniform(-0.1, 1.1, (M, D))
+    c, ls, noise, jit = 0.1, np.array([0.1] * 3), 1e-4, 1e-10
+    h = _lib.Handle(0)
+    h.fit(X, Y, ls, c, noise, jit)
+    _, alpha = h.export(want_L=False)
+    tr = h.predict_all(X, mean=True)["mean"]
+    assert_parity(tr, Y - (noise + jit) * alpha, 1e-7, "mean at the training points")
+    out = h.predict_all(Xq, mean=True, var=True, J=True)
+    assert np.all(np.isfinite(out["mean"])) and np.all(np.isfinite(out["J"]))
+    assert out["var"].min() >= 0.0 and out["var"].max() <= c + noise + 1e-12
+    sub = slice(0, 4096)
+    full = h.predict_all(Xq[sub], var=True, Jvar=True, dvar=True)
+    assert_parity(full["var"], out["var"][sub], 1e-10, "var: 4-column kernel vs 1-column kernel")
+    eps = 1e-5
+    for d in range(D):
+        e = np.zeros(D); e[d] = eps
+        p = h.predict_all(Xq[sub] + e, mean=True, var=True)
+        m = h.predict_all(Xq[sub] - e, mean=True, var=True)
+        assert_parity(out["J"][sub][:, :, d], (p["mean"] - m["mean"]) / (2 * eps), 1e-5, f"J[..., {d}] vs finite difference")
+        assert_parity(full["dvar"][d], (p["var"] - m["var"]) / (2 * eps), 1e-4, f"dvar[{d}] vs finite difference")
+    assert np.all(full["Jvar"] <= c / ls[0] ** 2 + 1e-9) and np.all(full["Jvar"] > -1e-6)
+    h.close()
+
+
+def test_device_pointer_api_and_model_handoff():
+    """gpt_predict_all_dev on torch tensors + the blob hand-off used for the multi-GPU broadcast
+    (alloc on a second handle, copy the bytes, commit) reproduce the host-pointer results."""
+    import torch
+    from gaussian_process_transportation_amd import _lib
+    from gaussian_process_transportation_amd.distributed import wrap_device_bytes
+    rng = np.random.default_rng(5)
+    N, M = 600, 3000
+    X = rng.uniform(0, 1, (N, 3)); Y = np.cos(3 * X); Xq = rng.uniform(0, 1, (M, 3))
+    h = _lib.Handle(0)
+    h.fit(X, Y, np.array([0.2, 0.3, 0.25]), 0.5, 1e-3, 1e-10)
+    ref = h.predict_all(Xq, mean=True, var=True, J=True, Jvar=True)
+    dev = torch.device("cuda", 0)
+    xq = torch.from_numpy(Xq).to(dev)
+    mean = torch.empty((M, 3), dtype=torch.float64, device=dev); var = torch.empty(M, dtype=torch.float64, device=dev)
+    J = torch.empty((M, 3, 3), dtype=torch.float64, device=dev); Jv = torch.empty((M, 3), dtype=torch.float64, device=dev)
+    h.set_stream(torch.cuda.current_stream().cuda_stream)
+    h.set_profiling(True)
+    h.predict_all_dev(xq.data_ptr(), M, mean.data_ptr(), var.data_ptr(), J.data_ptr(), Jv.data_ptr())
+    t = h.predict_timings()
+    assert t["var_ms"] > 0 and t["mean_jac_ms"] > 0
+    torch.cuda.synchronize()
+    for k, v in (("mean", mean), ("var", var), ("J", J), ("Jvar", Jv)):
+        assert np.array_equal(v.cpu().numpy(), ref[k]), k
+    # hand-off: a second handle receives the model bytes
+    src_ptr, nbytes = h.factor_blob()
+    h2 = _lib.Handle(0)
+    dst_ptr, nbytes2 = h2.factor_alloc(N, 3, 3)
+    assert nbytes == nbytes2
+    with pytest.raises(_lib.GptError):
+        h2.factor_commit()                           # nothing broadcast yet: header check fails
+    wrap_device_bytes(dst_ptr, nbytes, dev).copy_(wrap_device_bytes(src_ptr, nbytes, dev))
+    torch.cuda.synchronize()
+    h2.factor_commit()
+    out2 = h2.predict_all(Xq, mean=True, var=True, J=True, Jvar=True)
+    for k in ("mean", "var", "J", "Jvar"):
+        assert np.array_equal(out2[k], ref[k]), k
+    with pytest.raises(_lib.GptError):
+        h2.export()                                   # L lives only on the fitting handle
+    h.close(); h2.close()

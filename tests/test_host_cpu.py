@@ -1,0 +1,186 @@
+"""CPU-side tests: the C-ABI library loads and exports every symbol of include/gpt_hip.h, refuses to
+compute without a GPU, and the host logic (affine alignment, transport algebra, resampling,
+quaternions, sharding + gloo collectives) matches the golden vectors / oracle."""
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+
+from tests.conftest import ROOT, assert_parity, load_golden
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "gpt_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(gpt_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    import ctypes
+    from gaussian_process_transportation_amd import _lib
+    names = header_functions()
+    assert len(names) >= 20
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/gpt_hip.h but not exported"
+    assert sorted(_lib.SIGNATURES) == names, "ctypes table and header disagree"
+    assert b"gfx950" in _lib.load().gpt_version()
+
+
+def test_no_cpu_fallback():
+    from gaussian_process_transportation_amd import _lib, GaussianProcess
+    if _lib.load().gpt_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(_lib.GptError):
+        _lib.Handle(0)
+    from sklearn.gaussian_process.kernels import RBF, WhiteKernel, ConstantKernel as C
+    gp = GaussianProcess(kernel=C(1.0) * RBF(0.2) + WhiteKernel(1e-3), optimizer=None, verbose=False)
+    with pytest.raises(_lib.GptError):
+        gp.fit(np.random.rand(10, 2), np.random.rand(10, 2))
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "gaussian_process_transportation_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    assert len(re.findall(r"from oracle", bench)) == 1      # only inside cpu_baseline()
+
+
+def test_affine_transform_matches_golden():
+    from gaussian_process_transportation_amd import AffineTransform
+    g = load_golden("letterS_2d")
+    a = AffineTransform(verbose=False).fit(g["source"], g["target"])
+    assert_parity(a.rotation_matrix, g["rotation"], 1e-12, "R")
+    assert_parity(a.S_centroid, g["S_centroid"], 1e-14, "S centroid")
+    assert_parity(a.T_centroid, g["T_centroid"], 1e-14, "T centroid")
+    assert_parity(a.predict(g["source"]), g["gp_X"], 1e-12, "aligned source")
+    assert a.derivative(g["demo"]).shape == (400, 2, 2)
+    s = AffineTransform(do_scale=True, verbose=False).fit(g["source"], g["target"])
+    assert float(s.scale) == pytest.approx(float(g["scale2"]), rel=1e-12)
+    assert_parity(s.derivative(g["demo"][:3]), np.repeat(g["rotation"][None], 3, 0), 1e-12, "derivative ignores scale")
+    i = AffineTransform(do_rotation=False, verbose=False).fit(g["source"], g["target"])
+    assert np.array_equal(i.rotation_matrix, np.eye(2))
+    one = AffineTransform(verbose=False).fit(g["source"][:1], g["target"][:1])      # too few points -> identity
+    assert np.array_equal(one.rotation_matrix, np.eye(2))
+    # reflection branch: a mirrored target must still give det(R) = +1
+    mirrored = g["source"] * np.array([1.0, -1.0])
+    r = AffineTransform(verbose=False).fit(g["source"], mirrored)
+    assert np.linalg.det(r.rotation_matrix) == pytest.approx(1.0, abs=1e-12)
+    g3 = load_golden("surface_3d")
+    a3 = AffineTransform(verbose=False).fit(g3["source"], g3["target"])
+    assert_parity(a3.rotation_matrix, g3["rotation"], 1e-12, "R 3-D")
+
+
+def test_resample_matches_golden():
+    from gaussian_process_transportation_amd.utils import resample
+    g = load_golden("letterS_2d")
+    assert_parity(resample(g["demo_raw"], 400), g["demo"], 1e-12, "demo")
+    assert_parity(resample(g["floor_raw"], 20), g["source"], 1e-12, "floor")
+    assert_parity(resample(g["newfloor_raw"], 20), g["target"], 1e-12, "newfloor")
+
+
+class _OracleDeltaMap:
+    """Test double for the delta_map plugin slot: the CPU oracle behind the reference's method names."""
+
+    def __init__(self, g):
+        from oracle import gp_oracle as orc
+        self.o = orc.GaussianProcessOracle(g["constant_value"], g["length_scale"], g["noise_level"])
+
+    def fit(self, X, Y):
+        self.o.fit(X, Y)
+
+    def predict(self, x, return_std=False):
+        return self.o.predict(x, return_std=return_std)
+
+    def derivative(self, x, return_var=False):
+        return self.o.derivative(x, return_var=return_var)
+
+
+def test_policy_transportation_algebra_with_oracle_plugin():
+    """The duck-typed plugin boundary: PolicyTransportation around a CPU delta_map reproduces the
+    reference's transported trajectory / velocity / variance."""
+    from gaussian_process_transportation_amd import PolicyTransportation
+    g = load_golden("letterS_2d")
+    pt = PolicyTransportation(_OracleDeltaMap(g), verbose=False)
+    pt.fit(g["source"], g["target"])
+    traj, std = pt.transport(g["demo"])
+    vel, var_vel = pt.transport_velocity(g["demo"], g["delta"])
+    assert_parity(traj, g["traj"], 1e-9, "traj")
+    assert_parity(std, g["std"], 1e-7, "std")
+    assert_parity(vel, g["vel"], 1e-7, "vel")
+    assert_parity(var_vel, g["var_vel"], 1e-6, "var_vel")
+    traj2, none = pt.transport(g["demo"], return_std=False)
+    assert none is None and np.array_equal(traj2, traj)
+    vel2, none = pt.transport_velocity(g["demo"], g["delta"], return_var=False)
+    assert none is None and np.array_equal(vel2, vel)
+
+
+def test_quaternion_helpers():
+    from gaussian_process_transportation_amd.quaternion import (quaternion_from_nonorthogonal, quaternion_multiply,
+                                                                rotation_matrix_from_quaternion)
+    rng = np.random.default_rng(0)
+    q = rng.standard_normal((50, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True); q[q[:, 0] < 0] *= -1
+    R = rotation_matrix_from_quaternion(q)
+    assert_parity(quaternion_from_nonorthogonal(R), q, 1e-12, "q(R(q))")
+    # closest rotation of a perturbed matrix = polar factor
+    A = R + 0.05 * rng.standard_normal(R.shape)
+    U, _, Vt = np.linalg.svd(A)
+    polar = U @ Vt
+    qa = quaternion_from_nonorthogonal(A)
+    assert np.max(np.abs(rotation_matrix_from_quaternion(qa) - polar)) < 0.02
+    p = rng.standard_normal((50, 4)); p /= np.linalg.norm(p, axis=1, keepdims=True)
+    assert_parity(rotation_matrix_from_quaternion(quaternion_multiply(q, p)),
+                  R @ rotation_matrix_from_quaternion(p), 1e-12, "R(q p) = R(q) R(p)")
+
+
+def test_shard_range():
+    from gaussian_process_transportation_amd.distributed import shard_range
+    for M in (0, 1, 7, 500_000, 4_000_001):
+        for world in (1, 2, 3, 8):
+            edges = [shard_range(M, r, world) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == M
+            assert all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in edges]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_range(10, 2, 2)
+
+
+def _gloo_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from gaussian_process_transportation_amd.distributed import broadcast_geometry, gather_rows, shard_range
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        geom = broadcast_geometry((8192, 3, 3) if rank == 0 else None, src=0)
+        M = 1001
+        a, b = shard_range(M, rank, world)
+        full = np.arange(M * 3, dtype=np.float64).reshape(M, 3)
+        got = gather_rows(full[a:b] * 2.0, M)
+        q.put((rank, geom, bool(np.array_equal(got, full * 2.0))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_shard_and_gather():
+    """world_size-2 rehearsal (CPU, gloo) of the multi-GPU host logic: geometry broadcast from the fitting
+    rank, contiguous query shards, row gather."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, (8192, 3, 3), True), (1, (8192, 3, 3), True)]
