@@ -77,6 +77,8 @@ struct gpt_handle {
     hipEvent_t ev[7] = {};
     // per-kernel timing of the last predict (gpt_set_profiling)
     bool profiling = false, pred_mj = false, pred_var = false;
+    double* slab = nullptr;        // partial column sums of the variance kernel (grow-only)
+    size_t slab_cap = 0;
     hipEvent_t pev[4] = {};
 
     double* dXs() const { return blob + lay.off_xs; }
@@ -147,6 +149,7 @@ void fill_params(gpt_handle* h, const double* hdr) {
     KernelParams& p = h->p;
     p.N = (int)hdr[1]; p.NP = (int)hdr[2]; p.D = (int)hdr[3]; p.O = (int)hdr[4];
     p.c = hdr[5]; p.noise = hdr[6];
+    p.lnc = std::log(hdr[5]);
     h->jitter = hdr[7];
     h->n_ls = (int)hdr[11];
     for (int d = 0; d < 3; ++d) {
@@ -197,6 +200,7 @@ void gpt_destroy(gpt_handle* h) {
     free_staging(h);
     free_workspace(h);
     if (h->blob) (void)hipFree(h->blob);
+    if (h->slab) (void)hipFree(h->slab);
     for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : h->pev) if (ev) (void)hipEventDestroy(ev);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -308,9 +312,18 @@ int gpt_predict_all_dev(gpt_handle* h, const double* Xq, int64_t M, double* mean
         if (prof) HIPCHK(hipEventRecord(h->pev[1], s));
     }
     if (h->pred_var) {
+        const int ncomp = (Jvar || dvar) ? 4 : 1;
+        const size_t need = var_slab_doubles(M, ncomp);
+        if (need > h->slab_cap) {      // grow-only scratch; reallocation waits for work that may still use it
+            HIPCHK(hipStreamSynchronize(s));
+            if (h->slab) (void)hipFree(h->slab);
+            h->slab = nullptr; h->slab_cap = 0;
+            HIPCHK(hipMalloc(&h->slab, need * sizeof(double)));
+            h->slab_cap = need;
+        }
         if (prof) HIPCHK(hipEventRecord(h->pev[2], s));
-        if (Jvar || dvar) launch_var(s, h->p, h->dXs(), h->dWf(), Xq, M, 4, var, Jvar, dvar);
-        else launch_var(s, h->p, h->dXs(), h->dWf(), Xq, M, 1, var, nullptr, nullptr);
+        if (ncomp == 4) launch_var(s, h->p, h->dXs(), h->dWf(), Xq, M, 4, var, Jvar, dvar, h->slab);
+        else launch_var(s, h->p, h->dXs(), h->dWf(), Xq, M, 1, var, nullptr, nullptr, h->slab);
         if (prof) HIPCHK(hipEventRecord(h->pev[3], s));
     }
     HIPCHK(hipGetLastError());

@@ -11,13 +11,14 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 
 // ---- geometry --------------------------------------------------------------------------
 // N is padded to NP = multiple of PAD_N so that every blocked kernel sees whole tiles.
-constexpr int PAD_N = 256;
+constexpr int PAD_N = 512;
 // Tile edge of the packed, fragment-ordered inverse factor Wf (rows of W per i-block and
-// columns per k-block; square so that the block lower triangle packs cleanly).
-constexpr int WT = 128;
-constexpr int WT_K4 = WT / 4;                 // MFMA k-steps (depth 4) per tile
-constexpr int WT_RT = WT / 16;                // 16-row MFMA tiles per tile
-constexpr size_t WT_STEP_DOUBLES = (size_t)WT * 4;            // doubles per k4-step of one tile
+// columns per k-block; square so that the block lower triangle packs cleanly).  One workgroup
+// of the variance kernel sweeps a whole 512-row i-block: 8 waves x 64 rows ("row groups").
+constexpr int WT = 512;
+constexpr int WT_K4 = WT / 4;                 // MFMA k-steps (depth 4) per tile            (128)
+constexpr int WT_GROUPS = WT / 64;            // 64-row groups per tile, one per wave       (8)
+constexpr size_t WT_STEP_DOUBLES = (size_t)WT * 4;            // doubles per k4-step of one tile (2048)
 constexpr size_t WT_TILE_DOUBLES = (size_t)WT * WT;           // doubles per tile
 // Cholesky panel width / diagonal block size.
 constexpr int NB = 64;
@@ -25,6 +26,7 @@ constexpr int NB = 64;
 // Model parameters passed by value to the prediction kernels.
 struct KernelParams {
     double c;            // constant_value (prior variance)
+    double lnc;          // log(constant_value)
     double noise;        // WhiteKernel noise_level
     double inv_ls[3];    // 1/length_scale per input dimension (unused dims: 0)
     int D;               // input dims (1..3)
@@ -44,8 +46,10 @@ void launch_logdet(hipStream_t s, const double* K, int N, int NP, double* out);
 // predict
 void launch_mean_jac(hipStream_t s, const KernelParams& p, const double* Xs, const double* A4,
                      const double* Xq, int64_t M, double* mean, double* J);
+// `slab` is scratch of var_slab_doubles(M, ncomp) doubles (per-piece partial column sums)
 void launch_var(hipStream_t s, const KernelParams& p, const double* Xs, const double* Wf,
-                const double* Xq, int64_t M, int ncomp, double* var, double* Jvar, double* dvar);
+                const double* Xq, int64_t M, int ncomp, double* var, double* Jvar, double* dvar, double* slab);
+size_t var_slab_doubles(int64_t M, int ncomp);
 
 size_t wf_doubles(int NP);
 

@@ -371,46 +371,54 @@ void launch_alpha(hipStream_t s, const double* W, const double* Y4, int N, int N
 // =====================================================================================
 // Pack W (row-major, lower) into the fragment-ordered tile stream Wf.
 // Tile (ib, kb), kb <= ib, index ib(ib+1)/2 + kb, WT x WT doubles each, laid out
-//   [k4 = 0..WT/4)[q = 0..WT/32)[lane = 0..64)[p = 0..2)
-// holding W[ib*WT + 16*(2q+p) + (lane&15)][kb*WT + 4*k4 + (lane>>4)]  — i.e. the A operand
-// of v_mfma_f64_16x16x4_f64 for row tiles 2q, 2q+1, 16 B per lane, 1 KiB per wave load.
+//   [k4 = 0..WT/4)[g = 0..8)[q = 0..2)[lane = 0..64)[p = 0..2)
+// holding W[ib*WT + 64*g + 16*(2q+p) + (lane&15)][kb*WT + 4*k4 + (lane>>4)]  — i.e. for row group g
+// (the 64 rows one wave owns) the A operands of v_mfma_f64_16x16x4_f64 for its four 16-row tiles,
+// 16 B per lane and 2 KiB contiguous per wave and k4-step.
 // Rows/cols >= N (padding) are zeroed so padded sources never reach a variance.
+// One workgroup transposes a 128-row x 128-col sub-block through LDS (coalesced on both sides).
 // =====================================================================================
 size_t wf_doubles(int NP) {
     const size_t nb = NP / WT;
     return nb * (nb + 1) / 2 * WT_TILE_DOUBLES + WT_STEP_DOUBLES;   // + one k4-step of prefetch overrun
 }
 
-constexpr int PK_S = WT + 1;
+constexpr int PK = 128;          // sub-block edge
+constexpr int PK_S = PK + 1;
 
 __global__ __launch_bounds__(256) void k_pack_w(const double* __restrict__ W, int N, int NP, double* __restrict__ Wf) {
-    extern __shared__ __attribute__((aligned(16))) double tile[];   // [WT][PK_S]
-    const int ib = blockIdx.y, kb = blockIdx.x;
+    extern __shared__ __attribute__((aligned(16))) double tile[];   // [PK][PK_S]
+    constexpr int SUB = WT / PK;                 // sub-blocks per tile edge (4)
+    const int ib = blockIdx.y / SUB, rc = blockIdx.y % SUB;
+    const int kb = blockIdx.x / SUB, kc = blockIdx.x % SUB;
     if (kb > ib) return;
     const int t = threadIdx.x;
-    for (int e = t; e < WT * WT; e += 256) {
-        const int r = e / WT, c = e % WT;
-        const int gr = ib * WT + r, gc = kb * WT + c;
+    const int r0 = ib * WT + rc * PK, c0 = kb * WT + kc * PK;
+    for (int e = t; e < PK * PK; e += 256) {
+        const int r = e / PK, c = e % PK;
+        const int gr = r0 + r, gc = c0 + c;
         double v = 0.0;
         if (gr < N && gc < N && gc <= gr) v = W[(size_t)gr * NP + gc];
         tile[r * PK_S + c] = v;
     }
     __syncthreads();
-    double* out = Wf + ((size_t)ib * (ib + 1) / 2 + kb) * WT_TILE_DOUBLES;
-    constexpr int NQ = WT / 32;
-    for (int e = t; e < WT_K4 * NQ * 64; e += 256) {
-        const int lane = e & 63, q = (e >> 6) % NQ, k4 = e / (64 * NQ);
+    d2* out = reinterpret_cast<d2*>(Wf + ((size_t)ib * (ib + 1) / 2 + kb) * WT_TILE_DOUBLES);
+    // this sub-block covers k4 in [32 kc, 32 kc + 32), row groups g in {2 rc, 2 rc + 1}
+    for (int e = t; e < (PK / 4) * 2 * 2 * 64; e += 256) {
+        const int lane = e & 63, q = (e >> 6) & 1, gl = (e >> 7) & 1, k4l = e >> 8;
         const int lc = lane & 15, lk = lane >> 4;
-        const int col = 4 * k4 + lk;
-        const double v0 = tile[(16 * (2 * q) + lc) * PK_S + col];
-        const double v1 = tile[(16 * (2 * q + 1) + lc) * PK_S + col];
-        *reinterpret_cast<d2*>(out + (size_t)e * 2) = d2{v0, v1};
+        const int col = 4 * k4l + lk;
+        const int rowb = 64 * gl + 16 * (2 * q) + lc;
+        const double v0 = tile[rowb * PK_S + col];
+        const double v1 = tile[(rowb + 16) * PK_S + col];
+        const int k4 = (PK / 4) * kc + k4l, g = 2 * rc + gl;
+        out[((size_t)(k4 * WT_GROUPS + g) * 2 + q) * 64 + lane] = d2{v0, v1};
     }
 }
 
 void launch_pack_w(hipStream_t s, const double* W, int N, int NP, double* Wf) {
-    const int nb = NP / WT;
-    const size_t lds = (size_t)WT * PK_S * sizeof(double);
+    const int nb = NP / WT * (WT / PK);
+    const size_t lds = (size_t)PK * PK_S * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_pack_w), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
