@@ -36,6 +36,7 @@ SIGNATURES = {
     "gpt_export": (C.c_int, [_vp, _dp, _dp]),
     "gpt_export_inverse_factor": (C.c_int, [_vp, _dp]),
     "gpt_lml": (C.c_int, [_vp, _dp]),
+    "gpt_lml_gradient": (C.c_int, [_vp, _dp, _dp]),
     "gpt_factor_blob": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
     "gpt_factor_alloc": (C.c_int, [_vp, _i64, C.c_int, C.c_int, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
     "gpt_factor_commit": (C.c_int, [_vp]),
@@ -180,6 +181,12 @@ class Handle:
         v = C.c_double()
         check(self.lib.gpt_lml(self._h, C.byref(v)), "gpt_lml")
         return v.value
+
+    def lml_gradient(self, n_ls):
+        v = C.c_double()
+        g = np.zeros(2 + int(n_ls))
+        check(self.lib.gpt_lml_gradient(self._h, C.byref(v), dptr(g)), "gpt_lml_gradient")
+        return v.value, g
 
     def fit_timings(self):
         t = np.zeros(6)

@@ -79,6 +79,8 @@ struct gpt_handle {
     bool profiling = false, pred_mj = false, pred_var = false;
     double* slab = nullptr;        // partial column sums of the variance kernel (grow-only)
     size_t slab_cap = 0;
+    double* bscratch = nullptr;    // per-workgroup B-fragment images of the variance kernel (grow-only)
+    size_t bscratch_cap = 0;
     hipEvent_t pev[4] = {};
 
     double* dXs() const { return blob + lay.off_xs; }
@@ -201,6 +203,7 @@ void gpt_destroy(gpt_handle* h) {
     free_workspace(h);
     if (h->blob) (void)hipFree(h->blob);
     if (h->slab) (void)hipFree(h->slab);
+    if (h->bscratch) (void)hipFree(h->bscratch);
     for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : h->pev) if (ev) (void)hipEventDestroy(ev);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -321,9 +324,17 @@ int gpt_predict_all_dev(gpt_handle* h, const double* Xq, int64_t M, double* mean
             HIPCHK(hipMalloc(&h->slab, need * sizeof(double)));
             h->slab_cap = need;
         }
+        const size_t needb = var_bscratch_doubles(h->p.NP);
+        if (needb > h->bscratch_cap) {
+            HIPCHK(hipStreamSynchronize(s));
+            if (h->bscratch) (void)hipFree(h->bscratch);
+            h->bscratch = nullptr; h->bscratch_cap = 0;
+            HIPCHK(hipMalloc(&h->bscratch, needb * sizeof(double)));
+            h->bscratch_cap = needb;
+        }
         if (prof) HIPCHK(hipEventRecord(h->pev[2], s));
-        if (ncomp == 4) launch_var(s, h->p, h->dXs(), h->dWf(), Xq, M, 4, var, Jvar, dvar, h->slab);
-        else launch_var(s, h->p, h->dXs(), h->dWf(), Xq, M, 1, var, nullptr, nullptr, h->slab);
+        if (ncomp == 4) launch_var(s, h->p, h->dXs(), h->dWf(), Xq, M, 4, var, Jvar, dvar, h->slab, h->bscratch);
+        else launch_var(s, h->p, h->dXs(), h->dWf(), Xq, M, 1, var, nullptr, nullptr, h->slab, h->bscratch);
         if (prof) HIPCHK(hipEventRecord(h->pev[3], s));
     }
     HIPCHK(hipGetLastError());
@@ -425,6 +436,42 @@ int gpt_lml(gpt_handle* h, double* lml) {
         total += -0.5 * ya - logdet - 0.5 * (double)N * std::log(2.0 * M_PI);
     }
     *lml = total;
+    return GPT_OK;
+}
+
+int gpt_lml_gradient(gpt_handle* h, double* lml, double* grad) {
+    if (!h || !lml || !grad) return fail(GPT_E_ARG, "gpt_lml_gradient: NULL argument");
+    if (!h->committed || !h->have_factor_ws) return fail(GPT_E_STATE, "gpt_lml_gradient: needs the handle that ran gpt_fit");
+    if (int rc = gpt_lml(h, lml)) return rc;                    // uses diag(L) in dK before it is overwritten
+    const int64_t N = h->p.N, NP = h->p.NP;
+    const int D = h->p.D, O = h->p.O;
+    hipStream_t s = h->stream;
+    // K^-1 (lower) into dK, partial sums into the (currently idle) slab/partial scratch
+    const size_t need = (size_t)(NP / 64) * (NP / 64) * 8;
+    if (need > h->slab_cap) {
+        HIPCHK(hipStreamSynchronize(s));
+        if (h->slab) (void)hipFree(h->slab);
+        h->slab = nullptr; h->slab_cap = 0;
+        HIPCHK(hipMalloc(&h->slab, need * sizeof(double)));
+        h->slab_cap = need;
+    }
+    h->have_factor_ws = false;                                   // L is gone: gpt_export(L) needs a new gpt_fit
+    launch_kinv(s, h->dW, (int)NP, h->dK);
+    launch_lml_terms(s, h->dXs(), h->dA4(), h->lay.npass, h->dK, (int)N, (int)NP, O, h->p.c, h->slab, h->dscal);
+    HIPCHK(hipGetLastError());
+    double S[5];
+    HIPCHK(hipMemcpyAsync(S, h->dscal, sizeof S, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    // theta = log [constant_value, length_scale (1 or D), noise_level]
+    grad[0] = 0.5 * S[0];
+    if (h->n_ls == 1) {
+        double t = 0;
+        for (int d = 0; d < D; ++d) t += S[1 + d];
+        grad[1] = 0.5 * t;
+    } else {
+        for (int d = 0; d < D; ++d) grad[1 + d] = 0.5 * S[1 + d];
+    }
+    grad[1 + h->n_ls] = 0.5 * h->p.noise * S[4];
     return GPT_OK;
 }
 

@@ -43,13 +43,19 @@ void launch_trinv(hipStream_t s, const double* L, double* W, int NP, double* scr
 void launch_alpha(hipStream_t s, const double* W, const double* Y4, int N, int NP, double* tmp4, double* A4);
 void launch_pack_w(hipStream_t s, const double* W, int N, int NP, double* Wf);
 void launch_logdet(hipStream_t s, const double* K, int N, int NP, double* out);
+void launch_kinv(hipStream_t s, const double* W, int NP, double* Kout);
+void launch_lml_terms(hipStream_t s, const double* Xs, const double* A4, int npass, const double* Kinv, int N, int NP,
+                      int O, double c, double* partial /* (NP/64)^2*8 doubles */, double* out /* 5 doubles */);
 // predict
 void launch_mean_jac(hipStream_t s, const KernelParams& p, const double* Xs, const double* A4,
                      const double* Xq, int64_t M, double* mean, double* J);
-// `slab` is scratch of var_slab_doubles(M, ncomp) doubles (per-piece partial column sums)
+// `slab`: scratch of var_slab_doubles(M, ncomp) doubles (per-piece partial column sums);
+// `bscratch`: var_bscratch_doubles(NP) doubles (per-workgroup image of the generated B fragments)
 void launch_var(hipStream_t s, const KernelParams& p, const double* Xs, const double* Wf,
-                const double* Xq, int64_t M, int ncomp, double* var, double* Jvar, double* dvar, double* slab);
+                const double* Xq, int64_t M, int ncomp, double* var, double* Jvar, double* dvar, double* slab,
+                double* bscratch);
 size_t var_slab_doubles(int64_t M, int ncomp);
+size_t var_bscratch_doubles(int NP);
 
 size_t wf_doubles(int NP);
 

@@ -138,12 +138,14 @@ struct GemmArgs {
     int lower_only;          // skip tiles strictly above the block diagonal (SYRK)
     int a_lower;             // A lower triangular: k < i0 + 128
     int b_lower;             // B lower triangular (BT=false): k >= j0
+    int k_from_ij;           // both operands vanish for k < max(i0, j0) (W^T W with W lower triangular)
 };
 
 constexpr int GA_S = 34;     // [row][k] stride
 constexpr int GB_S = 144;    // [k][n] stride
 
-template <bool BT>
+// AT = true: A is given transposed, A(i,k) = Amem[k*lda + i] (used for K^-1 = W^T W).
+template <bool BT, bool AT = false>
 __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* As = smem;                // [128][GA_S]
@@ -162,6 +164,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
     int kbeg = 0, kend = K;
     if (g.a_lower) kend = min(K, i0 + 128);
     if (g.b_lower) kbeg = j0;
+    if (g.k_from_ij) kbeg = i0 > j0 ? i0 : j0;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int wr = w >> 1, wc = w & 1;
     const int lc = lane & 15, lk = lane >> 4;
@@ -173,13 +176,23 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
         for (int c = 0; c < 4; ++c) acc[r][c] = d4{0, 0, 0, 0};
 
     for (int kc = kbeg; kc < kend; kc += 32) {
-        {   // A chunk: 128 rows x 32 k; thread -> row t>>1, 16 consecutive k
+        if (!AT) {   // A chunk: 128 rows x 32 k; thread -> row t>>1, 16 consecutive k
             const int r = t >> 1, h = (t & 1) * 16;
             const bool ok = (i0 + r) < M;
             const d2* src = reinterpret_cast<const d2*>(A + (size_t)(i0 + r) * g.lda + kc + h);
             d2* dst = reinterpret_cast<d2*>(&As[r * GA_S + h]);
 #pragma unroll
             for (int u = 0; u < 8; ++u) dst[u] = ok ? src[u] : d2{0, 0};
+        } else {     // transposed source: thread -> k row t>>3, 16 consecutive i (coalesced), scattered into [i][k]
+            const int kr = t >> 3, sg = (t & 7) * 16;
+            const bool ok = (i0 + sg) < M;
+            const d2* src = reinterpret_cast<const d2*>(A + (size_t)(kc + kr) * g.lda + i0 + sg);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const d2 v = ok ? src[u] : d2{0, 0};
+                As[(sg + 2 * u) * GA_S + kr] = v[0];
+                As[(sg + 2 * u + 1) * GA_S + kr] = v[1];
+            }
         }
         if (BT) {
             const int r = t >> 1, h = (t & 1) * 16;
@@ -233,17 +246,17 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
             }
 }
 
-template <bool BT>
+template <bool BT, bool AT = false>
 static void launch_gemm(hipStream_t s, const GemmArgs& g) {
     const int Mmax = g.M > g.M_last ? g.M : g.M_last;
     dim3 grid((g.N + 127) / 128, (Mmax + 127) / 128, g.nbatch);
     constexpr size_t lds = (size_t)(128 * GA_S + (BT ? 128 * GA_S : 32 * GB_S)) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<BT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<BT, AT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_gemm<BT>, grid, dim3(256), lds, s, g);
+    hipLaunchKernelGGL((k_gemm<BT, AT>), grid, dim3(256), lds, s, g);
 }
 
 // =====================================================================================
@@ -426,6 +439,92 @@ void launch_pack_w(hipStream_t s, const double* W, int N, int NP, double* Wf) {
     }
     hipLaunchKernelGGL(k_pack_w, dim3(nb, nb), dim3(256), lds, s, W, N, NP, Wf);
     hipMemsetAsync(Wf + (wf_doubles(NP) - WT_STEP_DOUBLES), 0, WT_STEP_DOUBLES * sizeof(double), s);
+}
+
+// =====================================================================================
+// Gradient of the log-marginal likelihood (sklearn/_gpr.py:625-648):
+//   grad_p = 0.5 * sum_ij ( sum_o alpha_io alpha_jo - O * Kinv_ij ) * dK_ij/dtheta_p ,  theta = log params.
+// launch_kinv: Kinv = W^T W (lower block triangle, MFMA GEMM) into `Kout`.
+// k_lml_terms: one workgroup per 64x64 lower tile recomputes the RBF part of K from the scaled sources
+// and accumulates  S[0] = sum inner*Krbf (d/dlog c),  S[1+d] = sum inner*Krbf*(xs_id-xs_jd)^2 (d/dlog l_d),
+// S[4] = sum_i inner_ii (d/dlog noise, times noise on the host); off-diagonal elements count twice.
+// Per-workgroup partials are summed in a fixed order by k_sum_partials (deterministic).
+// =====================================================================================
+void launch_kinv(hipStream_t s, const double* W, int NP, double* Kout) {
+    GemmArgs g{};
+    g.A = W; g.lda = NP; g.B = W; g.ldb = NP; g.C = Kout; g.ldc = NP;
+    g.M = g.M_last = NP; g.N = NP; g.K = g.K_last = NP; g.nbatch = 1;
+    g.alpha = 1.0; g.beta = 0.0; g.lower_only = 1; g.k_from_ij = 1;
+    launch_gemm<false, true>(s, g);
+}
+
+__global__ __launch_bounds__(256) void k_lml_terms(const double* __restrict__ Xs, const double* __restrict__ A4, int npass,
+                                                   const double* __restrict__ Kinv, int N, int NP, int O, double c,
+                                                   double* __restrict__ partial /* [blocks][8] */) {
+    const int bi = blockIdx.y, bj = blockIdx.x;
+    const int t = threadIdx.x;
+    double S[5] = {0, 0, 0, 0, 0};
+    if (bj <= bi) {
+        const int r = t >> 2, cs = (t & 3) * 16;
+        const int i = bi * 64 + r;
+        if (i < N) {
+            const double xi0 = Xs[(size_t)i * 4], xi1 = Xs[(size_t)i * 4 + 1], xi2 = Xs[(size_t)i * 4 + 2];
+            for (int u = 0; u < 16; ++u) {
+                const int j = bj * 64 + cs + u;
+                if (j > i || j >= N) continue;
+                double aa = 0.0;
+                for (int ps = 0; ps < npass; ++ps) {
+                    const d4 ai = *reinterpret_cast<const d4*>(A4 + ((size_t)ps * NP + i) * 4);
+                    const d4 aj = *reinterpret_cast<const d4*>(A4 + ((size_t)ps * NP + j) * 4);
+                    aa += ai[0] * aj[0] + ai[1] * aj[1] + ai[2] * aj[2] + ai[3] * aj[3];
+                }
+                const double inner = aa - (double)O * Kinv[(size_t)i * NP + j];
+                const double wgt = (i == j) ? 1.0 : 2.0;
+                const double d0 = xi0 - Xs[(size_t)j * 4], d1 = xi1 - Xs[(size_t)j * 4 + 1], d2 = xi2 - Xs[(size_t)j * 4 + 2];
+                const double kr = c * exp(-0.5 * (d0 * d0 + d1 * d1 + d2 * d2));
+                const double v = wgt * inner * kr;
+                S[0] += v; S[1] += v * d0 * d0; S[2] += v * d1 * d1; S[3] += v * d2 * d2;
+                if (i == j) S[4] += inner;
+            }
+        }
+    }
+    __shared__ double red[256][5];
+#pragma unroll
+    for (int e = 0; e < 5; ++e) red[t][e] = S[e];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o)
+#pragma unroll
+            for (int e = 0; e < 5; ++e) red[t][e] += red[t + o][e];
+        __syncthreads();
+    }
+    if (t < 5) partial[((size_t)bi * gridDim.x + bj) * 8 + t] = red[0][t];
+}
+
+__global__ __launch_bounds__(256) void k_sum_partials(const double* __restrict__ partial, int nblocks, double* __restrict__ out) {
+    __shared__ double red[256][5];
+    double S[5] = {0, 0, 0, 0, 0};
+    for (int b = threadIdx.x; b < nblocks; b += 256)
+#pragma unroll
+        for (int e = 0; e < 5; ++e) S[e] += partial[(size_t)b * 8 + e];
+#pragma unroll
+    for (int e = 0; e < 5; ++e) red[threadIdx.x][e] = S[e];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o)
+#pragma unroll
+            for (int e = 0; e < 5; ++e) red[threadIdx.x][e] += red[threadIdx.x + o][e];
+        __syncthreads();
+    }
+    if (threadIdx.x < 5) out[threadIdx.x] = red[0][threadIdx.x];
+}
+
+// partial: (NP/64)^2 * 8 doubles of scratch; out: 5 doubles
+void launch_lml_terms(hipStream_t s, const double* Xs, const double* A4, int npass, const double* Kinv, int N, int NP,
+                      int O, double c, double* partial, double* out) {
+    const int nb = NP / 64;
+    hipLaunchKernelGGL(k_lml_terms, dim3(nb, nb), dim3(256), 0, s, Xs, A4, npass, Kinv, N, NP, O, c, partial);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, partial, nb * nb, out);
 }
 
 // sum(log(diag(L))) over the first N rows (LML, sklearn/_gpr.py:603).  One workgroup.

@@ -116,50 +116,65 @@ void launch_mean_jac(hipStream_t s, const KernelParams& p, const double* Xs, con
 // ------------------------------------------------------------------------------------------
 // Variance kernel.
 //
-// Measured on MI355X (profiles/r01_mfma_f64_vs_valu_probe.txt): v_mfma_f64_16x16x4_f64 issues every
-// 64 cycles per SIMD (77.7 TFLOP/s with 2 waves/SIMD), but every fp64 VALU instruction of the same
-// SIMD costs ~4.5 of those cycles — the fp64 matrix and vector paths share the DP units.  The design
-// therefore minimises fp64 VALU work per MFMA and keeps the rest off the critical path:
-//   * a workgroup (512 threads = 8 waves, 2 per SIMD) owns 64 columns and a whole 512-row i-block:
-//     wave w accumulates the 64x64 product of its 64-row group (16 MFMA tiles, 128 VGPRs);
-//   * the B operand (k* / dk_d columns, one fp64 exp each — table-driven, gpt_exp.h) is generated ONCE
-//     per workgroup per k-step: wave w produces the fragments of k-step w of the next 8-step chunk into a
-//     double-buffered 2 x 16 KiB LDS image already in MFMA lane order (one barrier per chunk), so a wave
-//     pays 4 exps per 128 MFMAs.  The generation sits in the MIDDLE of the wave's MFMA run and the two
-//     waves of a SIMD are staggered (after step 2 / after step 6), so a barrier release is followed by
-//     MFMAs at once and one wave's exp latency hides under its partner's MFMAs;
+// What the hardware does (measured on MI355X, profiles/r01_*):
+//   * v_mfma_f64_16x16x4_f64 issues every 64 cycles per SIMD: 77.7 TFLOP/s with 2 waves/SIMD at 2.4 GHz;
+//   * every fp64 VALU instruction of a SIMD takes ~4.5 cycles away from its fp64 MFMA stream (the fp64
+//     matrix and vector paths share the DP units), so B values must be generated once, not per wave;
+//   * a workgroup barrier every 8 k-steps costs ~4 %; once the matrix pipe is >90 % busy the chip lowers
+//     its clock (2.38 -> 2.18 GHz), so what is left is energy per MFMA: operands must come from close by
+//     (A from L2 with all workgroups walking W in step, B from LDS), not from HBM.
+// Design:
+//   * a workgroup (512 threads = 8 waves, 2 per SIMD) owns a 64-column block and sweeps the 512-row
+//     i-blocks, longest sweep first; wave w accumulates the 64x64 product of its 64-row group (16 MFMA
+//     tiles, 128 VGPRs) and folds it into per-column sums when the sweep ends, so V = W K*^T never
+//     touches memory;
+//   * the B operand of a sweep reaches the waves through a double-buffered LDS image in MFMA lane order,
+//     2 x 32 k-steps x 2 KiB = 128 KiB, one barrier per 32 k-steps.  Wave w fills k-steps w, w+8, w+16,
+//     w+24 of the next chunk from the middle of its own MFMA run (the two waves of a SIMD staggered).
+//     In the FIRST sweep of a block the fragments are generated (k* / dk_d columns, one table-driven fp64
+//     exp each, gpt_exp.h) and a copy goes to this workgroup's scratch image in HBM/L2 ([k-step][lane][4],
+//     4 MB at N=8192); the other sweeps reload them from there (2 KiB per k-step per workgroup) — so a
+//     block pays N exps per column, not N*(N/512+1)/2;
 //   * the A operand streams from the fragment-ordered image Wf with two 16-byte loads per lane and
-//     k-step, prefetched one step ahead; in the diagonal tile a wave skips the k-steps where its row
-//     group is entirely above the diagonal, and row groups are paired (0,7)(1,6)(2,5)(3,4) on the SIMDs
-//     so the skipped work is balanced;
-//   * when an i-block is finished its V rows are squared and folded into per-column sums, so
-//     V = W K*^T never touches memory;
-//   * work is split stream-K style: the (column block, i-block) units, costed 128*ib + 72 k-steps, are
-//     laid end to end and cut into P equal ranges, one persistent workgroup per CU; a range writes one
-//     partial row of column sums per column block it touches into a slab slot (p + cb, unique), and
-//     k_var_finalize adds the slots of a block in fixed order (deterministic, no atomics).
+//     k-step, one step ahead; in the diagonal tile a wave skips the k-steps where its row group is
+//     entirely above the diagonal, row groups paired (0,7)(1,6)(2,5)(3,4) on the SIMDs;
+//   * work split: rounds of whole blocks (all workgroups in step => W tiles are shared through L2), then
+//     a stream-K split of the leftover blocks; partial column sums go to unique slab slots and
+//     k_var_finalize adds them in fixed order (deterministic, no atomics).
+// Alternatives measured and dropped (profiles/r01_kvar_variant_ab.txt): per-wave B generation (v1, 53 TF),
+// 8-step chunks (-3.7 %), barrier-free sweeps with every wave reading B from the scratch image (-3 %: L2
+// hit rate 97 % -> 56 %, 3.4 TB/s from beyond L2, clock 2.18 GHz), deeper A prefetch (0 %).
 // NCOMP = 1: one column per query (k*).  NCOMP = 4: four columns per query (k*, dk_0, dk_1, dk_2).
 // ------------------------------------------------------------------------------------------
 constexpr int VAR_COLS = 64;        // columns per column block
-constexpr int VAR_CH = 8;           // k4-steps per LDS chunk (= waves per workgroup)
-constexpr int VAR_DIAG_COST = 72;   // k4-steps a diagonal tile costs its slowest SIMD (16 + 128 of 2 x 128)
+constexpr int VAR_SUB = 8;          // k4-steps per sub-chunk (= waves per workgroup: wave w fills step w of each)
+constexpr int VAR_SUBS = 4;         // sub-chunks per LDS chunk
+constexpr int VAR_CH = VAR_SUB * VAR_SUBS;   // k4-steps per LDS chunk, one barrier each (32)
+constexpr size_t VAR_LDS_BYTES = (size_t)2 * VAR_CH * 64 * 4 * sizeof(double);   // 128 KiB
+constexpr int VAR_DIAG_COST = 96;   // k4-steps a diagonal tile costs (chunks of 32 in lock-step: 64+64+32+32 of 2 x 128, halved)
 constexpr int VAR_SLOT = 2 * VAR_COLS;   // doubles per slab slot: ssq[64], crs[64]
 
+// Work split.  Rounds 0..R-1: workgroup p takes the whole column block r*P + p — all workgroups then walk
+// the same W tiles at the same time, which is what keeps the W stream in L2 (each XCD's 32 workgroups
+// share one copy).  The ncb - R*P blocks left over ("tail") are laid end to end, costed per i-block, and
+// cut into P equal ranges (stream-K) so that every CU finishes together.
 struct VarPlan {
     int64_t ncb;     // column blocks
+    int64_t nfull;   // R * P blocks handled whole, round-robin
+    int64_t ncb_t;   // tail blocks = ncb - nfull
     int64_t T;       // cost of one column block (all i-blocks)
-    int64_t U;       // total cost = ncb * T
-    int P;           // workgroups (ranges)
+    int64_t U;       // tail cost = ncb_t * T
+    int P;           // workgroups
     int nbi;         // i-blocks
 };
 
-__host__ __device__ inline int64_t var_cost_prefix(int ib) {          // sum_{i<ib} (128 i + 72)
+__host__ __device__ inline int64_t var_cost_prefix(int ib) {          // sum_{i<ib} (128 i + VAR_DIAG_COST)
     return (int64_t)64 * ib * (ib - 1) + (int64_t)VAR_DIAG_COST * ib;
 }
 
-// first work unit (column block, i-block) of range p; p = P gives the end of the work
+// first work unit (tail column block, i-block) of tail range p; p = P gives the end of the tail
 __host__ __device__ inline void var_boundary(const VarPlan& pl, int p, int64_t& cb, int& ib) {
-    if (p >= pl.P) { cb = pl.ncb; ib = 0; return; }
+    if (p >= pl.P) { cb = pl.ncb_t; ib = 0; return; }
     const int64_t B = pl.U / pl.P * p + (pl.U % pl.P) * p / pl.P;
     cb = B / pl.T;
     const int64_t off = B % pl.T;
@@ -172,11 +187,19 @@ __host__ __device__ inline void var_boundary(const VarPlan& pl, int p, int64_t& 
     if (ib >= pl.nbi) { cb += 1; ib = 0; }
 }
 
+#define GPT_MFMA16(acc, a01, a23, b)                                                              \
+    _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) {                                            \
+        acc[0][t_] = __builtin_amdgcn_mfma_f64_16x16x4f64((a01)[0], (b)[t_], acc[0][t_], 0, 0, 0); \
+        acc[1][t_] = __builtin_amdgcn_mfma_f64_16x16x4f64((a01)[1], (b)[t_], acc[1][t_], 0, 0, 0); \
+        acc[2][t_] = __builtin_amdgcn_mfma_f64_16x16x4f64((a23)[0], (b)[t_], acc[2][t_], 0, 0, 0); \
+        acc[3][t_] = __builtin_amdgcn_mfma_f64_16x16x4f64((a23)[1], (b)[t_], acc[3][t_], 0, 0, 0); \
+    }
+
 template <int NCOMP, bool CROSS>
 __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlan pl, const double* __restrict__ Xs,
                                                 const double* __restrict__ Wf, const double* __restrict__ Xq,
-                                                int64_t M, double* __restrict__ slab) {
-    __shared__ __attribute__((aligned(16))) double Bs[2][VAR_CH][64][4];   // [buffer][k4-step][lane][column tile]
+                                                int64_t M, double* __restrict__ slab, double* __restrict__ bscratch) {
+    extern __shared__ __attribute__((aligned(16))) double Bs_dyn[];       // [buffer][k4-step][lane][column tile]
     __shared__ double red[2][8][VAR_COLS];
     __shared__ double Tt[256];
     const int lane = threadIdx.x & 63;
@@ -184,11 +207,13 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlan pl, cons
     const int lc = lane & 15, lk = lane >> 4;
     const int g = (w < 4) ? w : (11 - w);     // row group of this wave: 0,1,2,3,7,6,5,4
     const int D = p.D;
+    auto Bs = [&](const int buf, const int step) -> double* { return Bs_dyn + ((size_t)(buf * VAR_CH + step) * 64 + lane) * 4; };
     if (threadIdx.x < 256) Tt[threadIdx.x] = g_exp2_table[threadIdx.x];
 
-    int64_t cb0, cb1; int ib0, ib1;
+    int64_t cb0, cb1; int ib0, ib1;            // this workgroup's range of the tail
     var_boundary(pl, blockIdx.x, cb0, ib0);
     var_boundary(pl, blockIdx.x + 1, cb1, ib1);
+    const int64_t rounds = pl.nfull / pl.P;
 
     constexpr double RS2 = 0.70710678118654752440;    // coordinates are pre-scaled by 1/sqrt(2): t = ln c - |d'|^2
     const int comp = (NCOMP == 1) ? 0 : (lc & 3);     // NCOMP=4: b = kv * (cb + sum_d cd[d] * d'_d)
@@ -199,14 +224,26 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlan pl, cons
     const double lnc = p.lnc;
     const int nbi = pl.nbi;
     // A stream in d2 units: element (step S, group g, q, lane) at ((S*8 + g)*2 + q)*64 + lane
-    const d2* wbase = reinterpret_cast<const d2*>(Wf) + (size_t)g * 128 + lane;
+    const d2* const wbase = reinterpret_cast<const d2*>(Wf) + (size_t)g * 128 + lane;
     constexpr size_t STEP_D2 = WT_STEP_DOUBLES / 2;   // 1024
+    // this workgroup's B image in d2 units: k-step s, lane l at (s*64 + l)*2 (+1)
+    d2* const bimg = reinterpret_cast<d2*>(bscratch) + (size_t)blockIdx.x * ((size_t)p.NP * 32) + (size_t)lane * 2;
 
-    for (int64_t cb = cb0; cb <= cb1; ++cb) {
-        const int lo = (cb == cb0) ? ib0 : 0;
-        const int hi = (cb == cb1) ? ib1 : nbi;
-        if (cb >= pl.ncb || lo >= hi) continue;        // uniform over the workgroup
+    for (int64_t piece = 0;; ++piece) {
+        int64_t cb, slot; int lo, hi;
+        if (piece < rounds) {                          // whole block, in step with every other workgroup
+            cb = piece * pl.P + blockIdx.x; slot = cb; lo = 0; hi = nbi;
+        } else {                                       // this workgroup's share of the tail
+            const int64_t cbt = cb0 + (piece - rounds);
+            if (cbt > cb1 || cbt >= pl.ncb_t) break;
+            lo = (cbt == cb0) ? ib0 : 0;
+            hi = (cbt == cb1) ? ib1 : nbi;
+            if (lo >= hi) continue;
+            cb = pl.nfull + cbt; slot = pl.nfull + blockIdx.x + cbt;
+        }
         __syncthreads();                               // LDS (Bs, red, Tt) free / ready
+        // the scratch image is about to be rewritten: drop the L1 lines of it this CU may still hold
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 
         // this lane's four columns (one per MFMA column tile): scaled query coordinates
         double q[4][3];
@@ -219,35 +256,55 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlan pl, cons
             for (int d = 0; d < 3; ++d) q[t][d] = (d < D) ? Xq[mm * D + d] * (p.inv_ls[d] * RS2) : 0.0;
         }
         double gx[3];                                  // coordinates of the source this wave generates next
-        auto fetch = [&](const int k4base) {
-            const double* xp = Xs + (size_t)((k4base + w) * 4 + lk) * 4;
-            gx[0] = xp[0]; gx[1] = xp[1]; gx[2] = xp[2];
-        };
-        auto generate = [&](const int buf) {           // B fragments of k-step (k4base + w) -> LDS
-            const double x0 = gx[0] * RS2, x1 = gx[1] * RS2, x2 = gx[2] * RS2;
-            d4 b;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const double d0 = x0 - q[t][0], d1 = x1 - q[t][1], d2_ = x2 - q[t][2];
-                double tt = fma(-d0, d0, lnc);
-                tt = fma(-d1, d1, tt);
-                tt = fma(-d2_, d2_, tt);
-                const double kv = exp_tab(tt, Tt);
-                b[t] = (NCOMP == 1) ? kv : kv * (cbv + cd[0] * d0 + cd[1] * d1 + cd[2] * d2_);
+        d2 bl[2];                                      // or the fragments it reloads next
+        auto fetch = [&](const int k4, const bool gen) {
+            if (gen) {
+                const double* xp = Xs + (size_t)(k4 * 4 + lk) * 4;
+                gx[0] = xp[0]; gx[1] = xp[1]; gx[2] = xp[2];
+            } else {
+                bl[0] = bimg[(size_t)k4 * 128]; bl[1] = bimg[(size_t)k4 * 128 + 1];
             }
-            *reinterpret_cast<d4*>(&Bs[buf][w][lane][0]) = b;
+        };
+        auto produce = [&](const int buf, const int k4, const bool gen) {   // B fragments of k-step k4 -> LDS (+ scratch)
+            double* dstl = Bs(buf, k4 % VAR_CH);
+            if (gen) {
+                const double x0 = gx[0] * RS2, x1 = gx[1] * RS2, x2 = gx[2] * RS2;
+                d4 b;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const double d0 = x0 - q[t][0], d1 = x1 - q[t][1], d2_ = x2 - q[t][2];
+                    double tt = fma(-d0, d0, lnc);
+                    tt = fma(-d1, d1, tt);
+                    tt = fma(-d2_, d2_, tt);
+                    const double kv = exp_tab(tt, Tt);
+                    b[t] = (NCOMP == 1) ? kv : kv * (cbv + cd[0] * d0 + cd[1] * d1 + cd[2] * d2_);
+                }
+                *reinterpret_cast<d4*>(dstl) = b;
+                d2* dst = bimg + (size_t)k4 * 128;
+                dst[0] = d2{b[0], b[1]};
+                dst[1] = d2{b[2], b[3]};
+            } else {
+                *reinterpret_cast<d2*>(dstl) = bl[0];
+                *reinterpret_cast<d2*>(dstl + 2) = bl[1];
+            }
         };
 
         double ssq[4] = {0.0, 0.0, 0.0, 0.0}, crs[4] = {0.0, 0.0, 0.0, 0.0};
-        size_t S_ib = (size_t)64 * lo * (lo + 1);      // stream index of the first k4-step of i-block lo
-        fetch(0);
-        generate(0);
-        d2 a_nxt[2];
-        a_nxt[0] = wbase[S_ib * STEP_D2]; a_nxt[1] = wbase[S_ib * STEP_D2 + 64];   // step 0 is active for every group
-        __syncthreads();
-
-        int it = 0;            // chunk counter (LDS buffer parity)
-        for (int ib = lo; ib < hi; ++ib) {
+        for (int ib = hi - 1; ib >= lo; --ib) {               // longest sweep first: it covers every source the others need
+            const bool gen = (ib == hi - 1);
+            if (!gen) {     // the scratch image of this block is complete: make it visible before reloading it
+                if (ib == hi - 2) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+                __syncthreads();
+            }
+            const size_t S_ib = (size_t)64 * ib * (ib + 1);   // stream index of the first k4-step of this sweep
+#pragma unroll
+            for (int j = 0; j < VAR_SUBS; ++j) {              // chunk 0: wave w fills steps w, w+8, w+16, w+24
+                fetch(j * VAR_SUB + w, gen);
+                produce(0, j * VAR_SUB + w, gen);
+            }
+            d2 a_nxt[2];
+            a_nxt[0] = wbase[S_ib * STEP_D2]; a_nxt[1] = wbase[S_ib * STEP_D2 + 64];   // step 0 is active for every group
+            __syncthreads();
             d4 acc[4][4];
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -257,33 +314,29 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlan pl, cons
             const int my_limit = ib * WT_K4 + 16 * (g + 1);     // first k4-step of the sweep with nothing left for this group
             const int nchunks = nk4 / VAR_CH;
             for (int ch = 0; ch < nchunks; ++ch) {
-                const int cur = it & 1;
-                const bool more = (ch + 1 < nchunks) || (ib + 1 < hi);
-                if (more) fetch((ch + 1 < nchunks) ? (ch + 1) * VAR_CH : 0);
-                const bool active = ch * VAR_CH < my_limit;    // my_limit is a multiple of 16: all or nothing
-                auto step = [&](const int s) {
-                    const int k4 = ch * VAR_CH + s;
-                    const d2 a01 = a_nxt[0], a23 = a_nxt[1];
-                    const size_t Sn = (k4 + 1 < my_limit) ? (S_ib + k4 + 1) : (S_ib + nk4);
-                    a_nxt[0] = wbase[Sn * STEP_D2]; a_nxt[1] = wbase[Sn * STEP_D2 + 64];
-                    const d4 b = *reinterpret_cast<const d4*>(&Bs[cur][s][lane][0]);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01[0], b[t], acc[0][t], 0, 0, 0);
-                        acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01[1], b[t], acc[1][t], 0, 0, 0);
-                        acc[2][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a23[0], b[t], acc[2][t], 0, 0, 0);
-                        acc[3][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a23[1], b[t], acc[3][t], 0, 0, 0);
-                    }
-                };
-                if (active) { step(0); step(1); }
-                if (more && w < 4) generate(cur ^ 1);
-                if (active) { step(2); step(3); step(4); step(5); }
-                if (more && w >= 4) generate(cur ^ 1);
-                if (active) { step(6); step(7); }
+                const int cur = ch & 1;
+                const bool more = (ch + 1 < nchunks);
+                for (int sub = 0; sub < VAR_SUBS; ++sub) {
+                    const int k0 = ch * VAR_CH + sub * VAR_SUB;                 // first k-step of this sub-chunk
+                    const int kn = (ch + 1) * VAR_CH + sub * VAR_SUB + w;       // the k-step this wave fills meanwhile
+                    if (more) fetch(kn, gen);
+                    const bool active = k0 < my_limit;          // my_limit is a multiple of 16: all or nothing
+                    auto step = [&](const int s) {
+                        const int k4 = k0 + s;
+                        const d2 a01 = a_nxt[0], a23 = a_nxt[1];
+                        const size_t Sn = S_ib + ((k4 + 1 < my_limit) ? (k4 + 1) : k4);
+                        a_nxt[0] = wbase[Sn * STEP_D2]; a_nxt[1] = wbase[Sn * STEP_D2 + 64];
+                        const d4 b = *reinterpret_cast<const d4*>(Bs(cur, sub * VAR_SUB + s));
+                        GPT_MFMA16(acc, a01, a23, b);
+                    };
+                    if (active) { step(0); step(1); }
+                    if (more && w < 4) produce(cur ^ 1, kn, gen);
+                    if (active) { step(2); step(3); step(4); step(5); }
+                    if (more && w >= 4) produce(cur ^ 1, kn, gen);
+                    if (active) { step(6); step(7); }
+                }
                 __syncthreads();
-                ++it;
             }
-            S_ib += nk4;
             // i-block finished: fold this wave's 64 rows of V into the per-column sums
 #pragma unroll
             for (int t = 0; t < 4; ++t)
@@ -296,6 +349,7 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlan pl, cons
                         if (CROSS) crs[t] += v * __shfl(v, lane & ~3);
                     }
         }
+
         // rows of a column are spread over the 4 lane groups lk = 0..3 and over the 8 waves
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -315,7 +369,7 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlan pl, cons
             double v = 0.0;
 #pragma unroll
             for (int ww = 0; ww < 8; ++ww) v += red[which][ww][cl];
-            slab[((size_t)blockIdx.x + (size_t)cb) * VAR_SLOT + threadIdx.x] = v;
+            slab[(size_t)slot * VAR_SLOT + threadIdx.x] = v;
         }
     }
 }
@@ -327,23 +381,27 @@ __global__ __launch_bounds__(64) void k_var_finalize(KernelParams p, VarPlan pl,
                                                      double* __restrict__ dvar) {
     const int64_t cb = blockIdx.x;
     const int cl = threadIdx.x;
-    // first range that can touch this block: boundaries are monotone in p and spaced U/P apart
-    int64_t pa64 = (cb * pl.T) * pl.P / pl.U - 2;       // B_p <= U p / P, so this p starts at or before the block
-    if (pa64 < 0) pa64 = 0;
-    if (pa64 > pl.P - 1) pa64 = pl.P - 1;
-    const int pa = (int)pa64;
     double s2 = 0.0, cr = 0.0;
-    for (int pp = pa; pp < pl.P; ++pp) {
-        int64_t cbs, cbe; int ibs, ibe;
-        var_boundary(pl, pp, cbs, ibs);
-        if (cbs > cb) break;
-        var_boundary(pl, pp + 1, cbe, ibe);
-        const int lo = (cbs == cb) ? ibs : 0;                       // cbs <= cb here
-        const int hi = (cbe > cb) ? pl.nbi : ((cbe == cb) ? ibe : 0);
-        if (lo >= hi) continue;
-        const double* sl = slab + ((size_t)pp + (size_t)cb) * VAR_SLOT;
-        s2 += sl[cl];
-        cr += sl[VAR_COLS + cl];
+    if (cb < pl.nfull) {                                  // handled whole by one workgroup: one slot
+        const double* sl = slab + (size_t)cb * VAR_SLOT;
+        s2 = sl[cl]; cr = sl[VAR_COLS + cl];
+    } else {                                              // tail: add the ranges that touched it, in range order
+        const int64_t cbt = cb - pl.nfull;
+        int64_t pa64 = (cbt * pl.T) * pl.P / pl.U - 2;    // B_p <= U p / P, so this p starts at or before the block
+        if (pa64 < 0) pa64 = 0;
+        if (pa64 > pl.P - 1) pa64 = pl.P - 1;
+        for (int pp = (int)pa64; pp < pl.P; ++pp) {
+            int64_t cbs, cbe; int ibs, ibe;
+            var_boundary(pl, pp, cbs, ibs);
+            if (cbs > cbt) break;
+            var_boundary(pl, pp + 1, cbe, ibe);
+            const int lo = (cbs == cbt) ? ibs : 0;                      // cbs <= cbt here
+            const int hi = (cbe > cbt) ? pl.nbi : ((cbe == cbt) ? ibe : 0);
+            if (lo >= hi) continue;
+            const double* sl = slab + (size_t)(pl.nfull + pp + cbt) * VAR_SLOT;
+            s2 += sl[cl];
+            cr += sl[VAR_COLS + cl];
+        }
     }
     const int D = p.D;
     const int64_t col = cb * VAR_COLS + cl;
@@ -378,9 +436,11 @@ static VarPlan make_plan(const KernelParams& p, int64_t M, int ncomp) {
     VarPlan pl;
     pl.nbi = p.NP / WT;
     pl.ncb = (M * ncomp + VAR_COLS - 1) / VAR_COLS;
-    pl.T = var_cost_prefix(pl.nbi);
-    pl.U = pl.ncb * pl.T;
     pl.P = var_workgroups();
+    pl.T = var_cost_prefix(pl.nbi);
+    pl.nfull = pl.ncb / pl.P * pl.P;
+    pl.ncb_t = pl.ncb - pl.nfull;
+    pl.U = pl.ncb_t * pl.T;
     return pl;
 }
 
@@ -389,17 +449,27 @@ size_t var_slab_doubles(int64_t M, int ncomp) {
     return (size_t)(ncb + var_workgroups() + 1) * VAR_SLOT;
 }
 
+size_t var_bscratch_doubles(int NP) { return (size_t)var_workgroups() * (size_t)NP * VAR_COLS; }
+
 void launch_var(hipStream_t s, const KernelParams& p, const double* Xs, const double* Wf,
-                const double* Xq, int64_t M, int ncomp, double* var, double* Jvar, double* dvar, double* slab) {
+                const double* Xq, int64_t M, int ncomp, double* var, double* Jvar, double* dvar, double* slab,
+                double* bscratch) {
     if (M <= 0) return;
     const VarPlan pl = make_plan(p, M, ncomp);
+    static bool attr_set = false;
+    if (!attr_set) {      // 128 KiB of dynamic LDS per workgroup
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_var<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)VAR_LDS_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_var<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)VAR_LDS_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_var<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)VAR_LDS_BYTES);
+        attr_set = true;
+    }
     const dim3 grid((unsigned)pl.P), fgrid((unsigned)pl.ncb);
     if (ncomp == 1) {
-        hipLaunchKernelGGL((k_var<1, false>), grid, dim3(512), 0, s, p, pl, Xs, Wf, Xq, M, slab);
+        hipLaunchKernelGGL((k_var<1, false>), grid, dim3(512), VAR_LDS_BYTES, s, p, pl, Xs, Wf, Xq, M, slab, bscratch);
         hipLaunchKernelGGL((k_var_finalize<1>), fgrid, dim3(64), 0, s, p, pl, slab, M, var, Jvar, dvar);
     } else {
-        if (dvar) hipLaunchKernelGGL((k_var<4, true>), grid, dim3(512), 0, s, p, pl, Xs, Wf, Xq, M, slab);
-        else hipLaunchKernelGGL((k_var<4, false>), grid, dim3(512), 0, s, p, pl, Xs, Wf, Xq, M, slab);
+        if (dvar) hipLaunchKernelGGL((k_var<4, true>), grid, dim3(512), VAR_LDS_BYTES, s, p, pl, Xs, Wf, Xq, M, slab, bscratch);
+        else hipLaunchKernelGGL((k_var<4, false>), grid, dim3(512), VAR_LDS_BYTES, s, p, pl, Xs, Wf, Xq, M, slab, bscratch);
         hipLaunchKernelGGL((k_var_finalize<4>), fgrid, dim3(64), 0, s, p, pl, slab, M, var, Jvar, dvar);
     }
 }

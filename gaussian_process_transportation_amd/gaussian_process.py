@@ -44,13 +44,20 @@ class _FittedView:
         self.kernel_ = None
         self.X_train_ = None
         self.y_train_ = None
-        self.log_marginal_likelihood_value_ = None
+        self._lml = None
 
     @property
     def alpha_(self):
         if self._alpha_ is None:
             self._alpha_ = self._o._handle.export(want_L=False)[1]
         return self._alpha_
+
+    @property
+    def log_marginal_likelihood_value_(self):
+        """LML of the fitted theta (sklearn/_gpr.py:335-341), evaluated on the device on first access."""
+        if self._lml is None:
+            self._lml = self._o._handle.lml()
+        return self._lml
 
     @property
     def L_(self):
@@ -92,6 +99,7 @@ class GaussianProcess:
             raise ValueError(f"The number of targets seen in `y` is different from the parameter `n_targets`. "
                              f"Got {self.n_outputs} != {self.n_targets}.")
         c, ls, noise = kernel_hyperparameters(self._kernel_in)
+        lml = None
         if self.optimizer is not None:
             from .hyperopt import optimize_hyperparameters
             c, ls, noise, lml = optimize_hyperparameters(self, c, ls, noise)
@@ -105,6 +113,7 @@ class GaussianProcess:
         fitted.set_params(**{_PARAM_C: c, _PARAM_LS: (ls.copy() if keep_array else float(ls[0])), _PARAM_NOISE: noise})
         self.kernel = fitted
         self.gp = _FittedView(self)
+        self.gp._lml = lml
         self.gp.kernel_ = fitted
         self.gp.X_train_ = self.X
         self.gp.y_train_ = self.Y

@@ -1,10 +1,86 @@
-"""Hyper-parameter search for GaussianProcess(optimizer='fmin_l_bfgs_b') — the reference delegates
-it to sklearn (GaussianProcessRegressor.fit, sklearn/_gpr.py:296-338: L-BFGS-B on the negative
-log-marginal likelihood from the kernel's theta plus n_restarts_optimizer log-uniform restarts
-drawn from the global numpy RNG).  SURVEY §8f row 1: not on the GPU path yet."""
+"""Hyper-parameter search for GaussianProcess(optimizer='fmin_l_bfgs_b').
+
+The reference delegates this to scikit-learn (`GaussianProcessRegressor.fit`,
+sklearn/gaussian_process/_gpr.py:296-338): L-BFGS-B on the negative log-marginal likelihood in
+theta = log(hyper-parameters), first from the kernel's own theta, then from `n_restarts_optimizer`
+starting points drawn log-uniformly inside the kernel's bounds with the GLOBAL numpy RNG
+(`random_state=None` -> `np.random.mtrand._rand`), keeping the best optimum.
+
+Here the driver is the same (scipy's L-BFGS-B on the host, same bounds, same RNG draws in the same
+order); every objective evaluation — Gram, Cholesky, alpha, K^-1 and the traces of the gradient
+(_gpr.py:537-652) — runs on the GPU (`gpt_fit` + `gpt_lml_gradient`).  The scikit-learn kernel object is
+used only as the container of theta / bounds / fixed flags."""
+from __future__ import annotations
+
+import warnings
+
+import numpy as np
+import scipy.optimize
+
+from . import _lib
+
+_PARAM_C = "k1__k1__constant_value"
+_PARAM_LS = "k1__k2__length_scale"
+_PARAM_NOISE = "k2__noise_level"
 
 
-def optimize_hyperparameters(gp, c, ls, noise):
-    raise NotImplementedError(
-        "optimizer='fmin_l_bfgs_b' (log-marginal-likelihood search) is not implemented on the GPU path yet; "
-        "construct GaussianProcess(..., optimizer=None) with fixed hyper-parameters.  There is no CPU fallback.")
+def _unpack(kernel, theta):
+    """theta (log-space, non-fixed hyper-parameters only) -> (c, ls array, noise) via a kernel clone."""
+    p = kernel.clone_with_theta(theta).get_params()
+    return float(p[_PARAM_C]), np.atleast_1d(np.asarray(p[_PARAM_LS], dtype=np.float64)), float(p[_PARAM_NOISE])
+
+
+def _free_mask(kernel, n_ls):
+    """Which entries of the full gradient [c, ls (n_ls), noise] belong to theta (hyper-parameters whose
+    bounds are not "fixed"), in theta order."""
+    mask = []
+    for hp in kernel.hyperparameters:
+        width = 1 if hp.n_elements == 1 else hp.n_elements
+        mask.extend([not hp.fixed] * width)
+    if len(mask) != 2 + n_ls:
+        raise ValueError("unexpected hyper-parameter layout for ConstantKernel * RBF + WhiteKernel")
+    return np.array(mask, dtype=bool)
+
+
+def optimize_hyperparameters(gp, c0, ls0, noise0):
+    """Returns (c, ls, noise, lml) maximising the log-marginal likelihood as sklearn would."""
+    kernel = gp._kernel_in
+    if kernel.n_dims == 0:
+        return c0, ls0, noise0, None
+    if gp.optimizer != "fmin_l_bfgs_b":
+        raise ValueError(f"Unknown optimizer {gp.optimizer}.")        # sklearn/_gpr.py:668-669 (callables: not supported here)
+    if gp._handle is None:
+        gp._handle = _lib.Handle(gp.device)
+    h = gp._handle
+    n_ls = int(np.size(ls0))
+    free = _free_mask(kernel, n_ls)
+    X, Y, jitter = gp.X, gp.Y, gp.alpha
+
+    def objective(theta):
+        c, ls, noise = _unpack(kernel, theta)
+        try:
+            h.fit(X, Y, ls, c, noise, jitter)
+            lml, grad = h.lml_gradient(n_ls)
+        except np.linalg.LinAlgError:                      # _gpr.py:587-590: -inf LML, zero gradient
+            return np.inf, np.zeros_like(theta)
+        return -lml, -grad[free]
+
+    def run(theta_init, bounds):
+        res = scipy.optimize.minimize(objective, theta_init, method="L-BFGS-B", jac=True, bounds=bounds)
+        if res.status != 0:                                # sklearn's _check_optimize_result("lbfgs", ...)
+            warnings.warn(f"lbfgs failed to converge (status={res.status}): {res.message}")
+        return res.x, res.fun
+
+    bounds = kernel.bounds
+    optima = [run(kernel.theta, bounds)]
+    if gp.n_restarts_optimizer > 0:
+        if not np.isfinite(bounds).all():
+            raise ValueError("Multiple optimizer restarts (n_restarts_optimizer>0) requires that all bounds are finite.")
+        rng = np.random.mtrand._rand                       # check_random_state(None): the global RandomState
+        for _ in range(gp.n_restarts_optimizer):
+            theta_initial = rng.uniform(bounds[:, 0], bounds[:, 1])
+            optima.append(run(theta_initial, bounds))
+    values = [v for _, v in optima]
+    best = int(np.argmin(values))
+    c, ls, noise = _unpack(kernel, optima[best][0])
+    return c, ls, noise, -values[best]

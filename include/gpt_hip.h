@@ -92,6 +92,11 @@ int gpt_export_inverse_factor(gpt_handle* h, double* W);
 /* Log-marginal likelihood of the fitted theta (sklearn/_gpr.py:598-606): sum over outputs of
  * -0.5 y^T alpha - sum(log diag L) - N/2 log(2 pi). */
 int gpt_lml(gpt_handle* h, double* lml);
+/* The same value plus its gradient with respect to theta = log [constant_value, length_scale (n_ls
+ * entries), noise_level] — what sklearn's optimizer consumes (sklearn/_gpr.py:625-648: 0.5 * trace((alpha
+ * alpha^T - K^-1) dK/dtheta) summed over outputs).  grad has 2 + n_ls entries.  Overwrites the Cholesky
+ * factor held for gpt_export (a later gpt_fit restores it). */
+int gpt_lml_gradient(gpt_handle* h, double* lml, double* grad);
 
 /* Multi-GPU hand-off of a fitted model (fit on rank 0, predict shards everywhere).  The model
  * is one contiguous device blob {header, scaled X, alpha, packed L^-1}:

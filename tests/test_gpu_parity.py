@@ -255,6 +255,85 @@ def test_full_size_properties():
     h.close()
 
 
+@pytest.mark.parametrize("name", ["synthetic_3d_N64", "synthetic_3d_N64_iso", "synthetic_3d_N256", "synthetic_3d_N1024"])
+def test_lml_value_and_gradient_vs_sklearn(name):
+    """gpt_lml_gradient against sklearn's log_marginal_likelihood(theta, eval_gradient=True) at three thetas."""
+    from gaussian_process_transportation_amd import _lib
+    g = load_golden(name)
+    n_ls = g["length_scale"].size
+    h = _lib.Handle(0)
+    for th, v, gr in zip(g["lml_theta"], g["lml_value"], g["lml_grad"]):
+        c, ls, noise = np.exp(th[0]), np.exp(th[1:1 + n_ls]), np.exp(th[1 + n_ls])
+        h.fit(g["X"], g["Y"], ls, c, noise, float(g["alpha"]))
+        lml, grad = h.lml_gradient(n_ls)
+        assert lml == pytest.approx(float(v), rel=1e-9)
+        assert_parity(grad, gr, 1e-6, "d lml / d theta")
+        with pytest.raises(_lib.GptError):
+            h.export()                      # the factor was consumed by the gradient; a new fit restores it
+        h.fit(g["X"], g["Y"], ls, c, noise, float(g["alpha"]))
+        assert h.export()[0].shape == (len(g["X"]), len(g["X"]))
+    h.close()
+
+
+def test_letterS_with_optimizer_matches_reference_fit():
+    """Config 1 end to end with the reference's default optimizer: same L-BFGS-B driver and RNG protocol as
+    sklearn, objective on the GPU.  Tolerance 1e-4: limited by the optimizer's own stopping tolerance."""
+    from gaussian_process_transportation_amd import GaussianProcessTransportation
+    g = load_golden("letterS_2d")
+    np.random.seed(0)
+    tr = GaussianProcessTransportation(kernel_transport=sk_kernel(10.0, 4 * np.ones(2), 0.01), verbose=False)
+    tr.source_distribution = g["source"]; tr.target_distribution = g["target"]
+    tr.training_traj = g["demo"]; tr.training_delta = g["delta"]
+    tr.fit_transportation(do_scale=False, do_rotation=True)
+    tr.apply_transportation()
+    gp = tr.method.delta_map
+    assert gp.gp.log_marginal_likelihood_value_ == pytest.approx(float(g["lml_fit"]), rel=1e-6)
+    assert_parity(np.asarray(gp.kernel.theta), g["theta_fit"], 1e-4, "fitted theta")
+    assert_parity(tr.training_traj, g["traj"], 1e-4, "traj")
+    assert_parity(tr.std, g["std"], 1e-3, "std")
+    assert_parity(tr.training_delta, g["vel"], 1e-4, "vel")
+    assert_parity(tr.var_vel_transported, g["var_vel"], 1e-3, "var_vel")
+
+
+def test_surface3d_with_optimizer_reaches_reference_optimum():
+    """The reference's 3-D demo with its default kernel and optimizer (279 s on 8 CPU cores): the GPU search
+    must reach an optimum at least as good as sklearn's and the same hyper-parameters."""
+    from gaussian_process_transportation_amd import GaussianProcess
+    from gaussian_process_transportation_amd.affine_transform import AffineTransform
+    g = load_golden("surface_3d")
+    aff = AffineTransform(verbose=False).fit(g["source"], g["target"])
+    src = aff.predict(g["source"])
+    np.random.seed(0)
+    gp = GaussianProcess(kernel=sk_kernel(0.1, [0.1], 1e-4), verbose=False)
+    gp.fit(src, g["target"] - src)
+    assert gp.gp.log_marginal_likelihood_value_ >= float(g["lml_fit"]) - 1e-6 * abs(float(g["lml_fit"]))
+    assert_parity(np.asarray(gp.kernel.theta), g["theta_fit"], 1e-3, "fitted theta")
+
+
+@pytest.mark.parametrize("N,M", [(1024, 150_000), (2500, 70_000)])
+def test_many_column_blocks_per_workgroup(N, M):
+    """Large M at moderate N: every persistent workgroup of the variance kernel walks many column blocks
+    (scratch image and LDS reuse across pieces, ranges cut inside a block).  A strided subset is checked
+    against the oracle, the rest through 1-column vs 4-column agreement."""
+    from gaussian_process_transportation_amd import _lib
+    from oracle import gp_oracle as orc
+    X, Y, Xq = orc.synthetic_problem(N, M)
+    c, ls, noise, jit = 0.1, np.array([0.1, 0.12, 0.09]), 1e-4, 1e-10
+    h = _lib.Handle(0)
+    h.fit(X, Y, ls, c, noise, jit)
+    out1 = h.predict_all(Xq, mean=True, var=True, J=True)
+    out4 = h.predict_all(Xq, var=True, Jvar=True, dvar=True)
+    assert_parity(out4["var"], out1["var"], 1e-11, "var: 4-column vs 1-column kernel")
+    idx = np.unique(np.r_[np.arange(0, M, 97), np.arange(M - 300, M), np.arange(0, 300)])
+    L, a = orc.gpr_fit(X, Y, c, ls, noise, jit)
+    mean, var, J, Jvar = orc.posterior_all_fast(Xq[idx], X, L, a, c, ls, noise, want_jvar=True)
+    assert_parity(out1["mean"][idx], mean, RTOL, "mean")
+    assert_parity(out1["var"][idx], var, RTOL, "var")
+    assert_parity(out1["J"][idx], J, RTOL, "J")
+    assert_parity(out4["Jvar"][idx], Jvar, RTOL, "Jvar")
+    h.close()
+
+
 def test_device_pointer_api_and_model_handoff():
     """gpt_predict_all_dev on torch tensors + the blob hand-off used for the multi-GPU broadcast
     (alloc on a second handle, copy the bytes, commit) reproduce the host-pointer results."""
