@@ -33,6 +33,7 @@ SIGNATURES = {
     "gpt_dvariance": (C.c_int, [_vp, _dp, _i64, _dp]),
     "gpt_predict_all": (C.c_int, [_vp, _dp, _i64, _dp, _dp, _dp, _dp, _dp]),
     "gpt_predict_all_dev": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "gpt_predict_cov": (C.c_int, [_vp, _dp, _i64, _dp, _dp]),
     "gpt_export": (C.c_int, [_vp, _dp, _dp]),
     "gpt_export_inverse_factor": (C.c_int, [_vp, _dp]),
     "gpt_lml": (C.c_int, [_vp, _dp]),
@@ -210,6 +211,16 @@ class Handle:
         check(self.lib.gpt_predict_all(self._h, dptr(Xq), M, dptr(out["mean"]), dptr(out["var"]), dptr(out["J"]),
                                        dptr(out["Jvar"]), dptr(out["dvar"])), "gpt_predict_all")
         return out
+
+    def predict_cov(self, Xq):
+        N, D, O, _ = self.info()
+        Xq = as_f64(Xq, 2)
+        if Xq.shape[1] != D:
+            raise ValueError(f"query has {Xq.shape[1]} features, model was fitted with {D}")
+        M = Xq.shape[0]
+        mean, cov = np.empty((M, O)), np.empty((M, M))
+        check(self.lib.gpt_predict_cov(self._h, dptr(Xq), M, dptr(mean), dptr(cov)), "gpt_predict_cov")
+        return mean, cov
 
     # ---- predict (device pointers, asynchronous)
     def predict_all_dev(self, xq_ptr, M, mean_ptr=0, var_ptr=0, J_ptr=0, Jvar_ptr=0, dvar_ptr=0):

@@ -439,6 +439,38 @@ int gpt_lml(gpt_handle* h, double* lml) {
     return GPT_OK;
 }
 
+int gpt_predict_cov(gpt_handle* h, const double* Xq, int64_t M, double* mean, double* cov) {
+    if (!h || !cov) return fail(GPT_E_ARG, "gpt_predict_cov: NULL argument");
+    if (!h->committed) return fail(GPT_E_STATE, "predict: model is not fitted");
+    if (!h->dW || h->ws_np != h->p.NP) return fail(GPT_E_STATE, "gpt_predict_cov: needs the handle that ran gpt_fit");
+    if (M < 0 || (M > 0 && !Xq)) return fail(GPT_E_ARG, "predict: bad query buffer");
+    if (M > 16384) return fail(GPT_E_ARG, "gpt_predict_cov: M x M covariance limited to M <= 16384");
+    if (M == 0) return GPT_OK;
+    if (int rc = set_device(h)) return rc;
+    if (mean) { if (int rc = gpt_predict_all(h, Xq, M, mean, nullptr, nullptr, nullptr, nullptr)) return rc; }
+    const int D = h->p.D;
+    const int64_t NP = h->p.NP;
+    const int Mp = (int)((M + 127) / 128 * 128);
+    hipStream_t s = h->stream;
+    double *dq = nullptr, *KsT = nullptr, *V = nullptr, *VtV = nullptr, *dcov = nullptr;
+    auto cleanup = [&]() { for (double* ptr : {dq, KsT, V, VtV, dcov}) if (ptr) (void)hipFree(ptr); };
+    hipError_t e = hipSuccess;
+    if ((e = hipMalloc(&dq, (size_t)M * D * sizeof(double))) == hipSuccess &&
+        (e = hipMalloc(&KsT, (size_t)NP * Mp * sizeof(double))) == hipSuccess &&
+        (e = hipMalloc(&V, (size_t)NP * Mp * sizeof(double))) == hipSuccess &&
+        (e = hipMalloc(&VtV, (size_t)Mp * Mp * sizeof(double))) == hipSuccess &&
+        (e = hipMalloc(&dcov, (size_t)M * M * sizeof(double))) == hipSuccess &&
+        (e = hipMemcpyAsync(dq, Xq, (size_t)M * D * sizeof(double), hipMemcpyHostToDevice, s)) == hipSuccess) {
+        launch_cov(s, h->p, h->dXs(), h->dW, dq, M, Mp, KsT, V, VtV, dcov);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(cov, dcov, (size_t)M * M * sizeof(double), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+    }
+    cleanup();
+    if (e != hipSuccess) return fail(GPT_E_HIP, std::string("gpt_predict_cov: ") + hipGetErrorString(e));
+    return GPT_OK;
+}
+
 int gpt_lml_gradient(gpt_handle* h, double* lml, double* grad) {
     if (!h || !lml || !grad) return fail(GPT_E_ARG, "gpt_lml_gradient: NULL argument");
     if (!h->committed || !h->have_factor_ws) return fail(GPT_E_STATE, "gpt_lml_gradient: needs the handle that ran gpt_fit");

@@ -44,6 +44,8 @@ void launch_alpha(hipStream_t s, const double* W, const double* Y4, int N, int N
 void launch_pack_w(hipStream_t s, const double* W, int N, int NP, double* Wf);
 void launch_logdet(hipStream_t s, const double* K, int N, int NP, double* out);
 void launch_kinv(hipStream_t s, const double* W, int NP, double* Kout);
+void launch_cov(hipStream_t s, const KernelParams& p, const double* Xs, const double* W, const double* Xq_dev, int64_t M,
+                int Mp, double* KsT /* NP*Mp */, double* V /* NP*Mp */, double* VtV /* Mp*Mp */, double* cov_dev /* M*M */);
 void launch_lml_terms(hipStream_t s, const double* Xs, const double* A4, int npass, const double* Kinv, int N, int NP,
                       int O, double c, double* partial /* (NP/64)^2*8 doubles */, double* out /* 5 doubles */);
 // predict

@@ -527,6 +527,65 @@ void launch_lml_terms(hipStream_t s, const double* Xs, const double* A4, int npa
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, partial, nb * nb, out);
 }
 
+// =====================================================================================
+// Posterior covariance  cov = k(Xq,Xq) + noise*I - V^T V,  V = W K*^T  (sklearn/_gpr.py:458-468,
+// where V = L \ K*^T).  Small-M path (sampling, return_cov): K*^T and V are materialised (NP x Mp).
+// =====================================================================================
+__global__ __launch_bounds__(256) void k_cross_t(const double* __restrict__ Xs, const double* __restrict__ Xq, int N, int NP,
+                                                 int64_t M, int Mp, int D, double c, double il0, double il1, double il2,
+                                                 double* __restrict__ KsT /* [NP][Mp] */) {
+    const int t = threadIdx.x;
+    const int n = blockIdx.y * 64 + (t >> 2);
+    const int m0 = blockIdx.x * 64 + (t & 3) * 16;
+    const double x0 = Xs[(size_t)n * 4], x1 = Xs[(size_t)n * 4 + 1], x2 = Xs[(size_t)n * 4 + 2];
+    for (int u = 0; u < 16; ++u) {
+        const int m = m0 + u;
+        double v = 0.0;
+        if (n < N && m < M) {
+            const double q0 = Xq[(size_t)m * D] * il0;
+            const double q1 = D > 1 ? Xq[(size_t)m * D + 1] * il1 : 0.0;
+            const double q2 = D > 2 ? Xq[(size_t)m * D + 2] * il2 : 0.0;
+            const double d0 = x0 - q0, d1 = x1 - q1, d2 = x2 - q2;
+            v = c * exp(-0.5 * (d0 * d0 + d1 * d1 + d2 * d2));
+        }
+        KsT[(size_t)n * Mp + m] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cov_finish(const double* __restrict__ Xq, int64_t M, int Mp, int D, double c, double noise,
+                                                    double il0, double il1, double il2, const double* __restrict__ VtV,
+                                                    double* __restrict__ cov /* [M][M] */) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= M * M) return;
+    const int64_t i = e / M, j = e % M;
+    double d2 = 0.0;
+    const double il[3] = {il0, il1, il2};
+    for (int d = 0; d < D; ++d) { const double df = (Xq[i * D + d] - Xq[j * D + d]) * il[d]; d2 += df * df; }
+    double v = (i == j) ? (c + noise) : c * exp(-0.5 * d2);      // RBF diagonal is exactly 1 (kernels.py:1562)
+    cov[e] = v - VtV[(size_t)i * Mp + j];
+}
+
+// scratch: KsT (NP*Mp), V (NP*Mp), VtV (Mp*Mp) doubles
+void launch_cov(hipStream_t s, const KernelParams& p, const double* Xs, const double* W, const double* Xq_dev, int64_t M,
+                int Mp, double* KsT, double* V, double* VtV, double* cov_dev) {
+    const int NP = p.NP;
+    hipLaunchKernelGGL(k_cross_t, dim3(Mp / 64, NP / 64), dim3(256), 0, s, Xs, Xq_dev, p.N, NP, M, Mp, p.D, p.c,
+                       p.inv_ls[0], p.inv_ls[1], p.inv_ls[2], KsT);
+    GemmArgs a{};
+    a.A = W; a.lda = NP; a.B = KsT; a.ldb = Mp; a.C = V; a.ldc = Mp;
+    a.M = a.M_last = NP; a.N = Mp; a.K = a.K_last = NP; a.nbatch = 1;
+    a.alpha = 1.0; a.beta = 0.0; a.a_lower = 1;
+    launch_gemm<false>(s, a);
+    GemmArgs b{};
+    b.A = V; b.lda = Mp; b.B = V; b.ldb = Mp; b.C = VtV; b.ldc = Mp;
+    b.M = b.M_last = Mp; b.N = Mp; b.K = b.K_last = NP; b.nbatch = 1;
+    b.alpha = 1.0; b.beta = 0.0;
+    launch_gemm<false, true>(s, b);
+    const int64_t tot = M * M;
+    hipLaunchKernelGGL(k_cov_finish, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, Xq_dev, M, Mp, p.D, p.c, p.noise,
+                       p.inv_ls[0], p.inv_ls[1], p.inv_ls[2], VtV, cov_dev);
+}
+
 // sum(log(diag(L))) over the first N rows (LML, sklearn/_gpr.py:603).  One workgroup.
 __global__ __launch_bounds__(256) void k_logdet(const double* __restrict__ K, int N, int NP, double* __restrict__ out) {
     __shared__ double red[256];

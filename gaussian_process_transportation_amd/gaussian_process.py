@@ -144,8 +144,11 @@ class GaussianProcess:
         self._require_fit()
         if return_std and return_cov:
             raise RuntimeError("At most one of return_std or return_cov can be requested.")
-        if return_cov:
-            raise NotImplementedError("return_cov (M x M posterior covariance) is not on the GPU path yet")
+        if return_cov:                                  # sklearn/_gpr.py:458-470
+            mean, cov = self._handle.predict_cov(x)
+            if self.n_outputs == 1:
+                return mean[:, 0], cov
+            return mean, np.repeat(cov[:, :, None], self.n_outputs, axis=2)
         out = self._handle.predict_all(x, mean=True, var=bool(return_std))
         mean = out["mean"]
         if self.n_outputs == 1:
@@ -158,7 +161,15 @@ class GaussianProcess:
         return mean, std - np.sqrt(self._noise)     # reference quirk (:49)
 
     def samples(self, x):
-        raise NotImplementedError("samples() (posterior draws over an M x M covariance) is not on the GPU path yet")
+        """(:57-60)  10 joint posterior draws per output, shape (10, M, O).  Mean and covariance come from the
+        GPU; the draws follow sklearn's sample_y (sklearn/_gpr.py:498-535: RandomState(0),
+        multivariate_normal per target) on the host."""
+        self._require_fit()
+        mean, cov = self._handle.predict_cov(x)
+        rng = np.random.RandomState(0)
+        per_target = [rng.multivariate_normal(mean[:, t], cov, 10).T[:, np.newaxis] for t in range(self.n_outputs)]
+        y_samples = np.hstack(per_target)               # (M, O, 10)
+        return np.transpose(y_samples, (2, 0, 1))
 
     # ------------------------------------------------------------------ derivatives
     def derivative(self, x, return_var=False):

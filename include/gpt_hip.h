@@ -83,6 +83,12 @@ int gpt_predict_all(gpt_handle* h, const double* Xq, int64_t M, double* mean, do
 int gpt_predict_all_dev(gpt_handle* h, const double* Xq_dev, int64_t M, double* mean_dev,
                         double* var_dev, double* J_dev, double* Jvar_dev, double* dvar_dev);
 
+/* predict(return_cov=True) — replaces sklearn/_gpr.py:458-470: mean (M,O) (may be NULL) and the joint
+ * posterior covariance cov (M,M) = k(Xq,Xq) + noise_level*I - V^T V, V = L^-1 K*^T (identical for every
+ * output; the caller tiles it).  Small-M path used by GaussianProcess.samples (gaussian_process.py:57-60);
+ * M <= 16384; needs the handle that ran gpt_fit.  Host memory. */
+int gpt_predict_cov(gpt_handle* h, const double* Xq, int64_t M, double* mean, double* cov);
+
 /* Parity-test export of sklearn's fitted attributes: L (N,N) lower triangular (zeros above),
  * alpha (N,O).  Either may be NULL.  Host memory. */
 int gpt_export(gpt_handle* h, double* L, double* alpha);

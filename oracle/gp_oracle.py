@@ -170,6 +170,16 @@ class GaussianProcessOracle:
             return gpr_predict(*args, return_cov=True)
         return gpr_predict(*args)
 
+    def samples(self, x, n_samples=10):
+        """ref: gaussian_process.py:57-60 -> sklearn/_gpr.py:498-535 (sample_y, random_state=0):
+        per target multivariate_normal(mean, cov) draws from RandomState(0); (n_samples, M, O)."""
+        mean, cov = self.predict(x, return_cov=True)
+        rng = np.random.RandomState(0)
+        if mean.ndim == 1:
+            return rng.multivariate_normal(mean, cov, n_samples).T
+        ys = [rng.multivariate_normal(mean[:, t], cov[..., t], n_samples).T[:, np.newaxis] for t in range(mean.shape[1])]
+        return np.transpose(np.hstack(ys), (2, 0, 1))
+
     def _dk(self, x):
         """dk[d,m,n] = (X[n,d]-x[m,d]) / l_d^2 * k(x_m, X_n).  ref: :72-87."""
         lscale = self.length_scale.reshape(-1, 1)

@@ -71,6 +71,7 @@ def gp_outputs(gp, Xq, with_L=True, with_cov=0, with_jvar=True):
     if with_cov:
         _, cov = gp.predict(Xq[:with_cov], return_cov=True)
         out["cov"] = cov
+        out["samples"] = gp.samples(Xq[:with_cov])          # (10, with_cov, O), RandomState(0) inside sklearn
     out["noise_var_"] = np.float64(gp.noise_var_)
     out["prior_var"] = np.float64(gp.prior_var)
     return out
@@ -131,6 +132,8 @@ def case_letterS(pt, resample):
                gp_X=gp.X, gp_Y=gp.Y, theta0=gp.gp.kernel.theta, theta_fit=gp.gp.kernel_.theta,
                bounds=gp.gp.kernel.bounds, lml_fit=np.float64(gp.gp.log_marginal_likelihood_value_),
                noise_var_=np.float64(gp.noise_var_), alpha=np.float64(1e-10), **theta_of(gp))
+    out["samples"] = tr.sample_transportation()[:, ::8, :]   # (10, 50, 2): every 8th trajectory point of the 400
+    out["samples_full_shape"] = np.array(tr.sample_transportation().shape)
     # second transport with do_scale=True, fixed hyper-parameters (affine scale branch)
     np.random.seed(0)
     tr2 = pt.GaussianProcessTransportation(kernel_transport=kern(out["constant_value"],

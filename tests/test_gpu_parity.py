@@ -69,6 +69,12 @@ def test_golden_predict_and_derivatives(name):
     assert_parity(J, g["J"], RTOL, "J")
     assert_parity(Jv, g["Jvar"], RTOL, "Jvar")
     assert_parity(gp.derivative_of_variance(Xq), g["dvar"], RTOL, "dvar")
+    if "cov" in g:
+        n = g["cov"].shape[0]
+        m, cov = gp.predict(Xq[:n], return_cov=True)
+        assert_parity(m, g["mean"][:n], RTOL, "mean (return_cov)")
+        assert_parity(cov, g["cov"], RTOL, "posterior covariance")
+        assert_parity(gp.samples(Xq[:n]), g["samples"], 1e-4, "samples (10 joint draws per output)")
     post = gp.posterior(Xq, jacobian_variance=True)
     assert_parity(post["mean"], g["mean"], RTOL, "fused mean")
     assert_parity(np.sqrt(post["var"]) - np.sqrt(float(g["noise_level"])), g["std"][:, 0], RTOL, "fused std")
@@ -125,6 +131,15 @@ def test_letterS_transport_fixed_theta():
     assert_parity(tr.training_delta, g["vel"], RTOL, "vel")
     assert_parity(tr.var_vel_transported, g["var_vel"], RTOL, "var_vel")
     assert tr.training_traj_old is g["demo"]
+    smp = tr.sample_transportation()
+    assert smp.shape == tuple(g["samples_full_shape"])
+    # 400 closely spaced points under a smooth kernel: the posterior covariance has a large eigenspace
+    # degenerate at ~noise_level, where the SVD basis used by multivariate_normal is arbitrary, so draws
+    # differ between implementations by O(sqrt(noise_level)) there (the well-conditioned N=64 case above is
+    # held to 1e-4).  Here: same shape, and every draw within 6 posterior standard deviations of sklearn's.
+    sd = np.sqrt(np.maximum(np.diag(tr.method.delta_map.predict(tr.method.affine_transform.predict(g["demo"]),
+                                                               return_cov=True)[1][:, :, 0]), 0))[::8]
+    assert np.all(np.abs(smp[:, ::8, :] - g["samples"]) <= 6 * np.sqrt(2) * sd[None, :, None] + 1e-9)
     tr2 = _transport(g, do_scale=True)
     assert float(tr2.method.affine_transform.scale) == pytest.approx(float(g["scale2"]), rel=1e-12)
     assert_parity(tr2.training_traj, g["traj2"], RTOL, "traj2")

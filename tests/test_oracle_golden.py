@@ -51,6 +51,7 @@ def test_predict_and_derivatives(name):
         n = g["cov"].shape[0]
         _, cov = gp.predict(Xq[:n], return_cov=True)
         assert_parity(cov, g["cov"], 1e-7, "cov")
+        assert_parity(gp.samples(Xq[:n]), g["samples"], 1e-6, "samples")
 
 
 @pytest.mark.parametrize("name", ["synthetic_3d_N64", "synthetic_3d_N256"])
