@@ -10,7 +10,7 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgpt_hip.so")
+LIB_PATH = os.environ.get("GPT_HIP_LIB") or os.path.join(_HERE, "libgpt_hip.so")   # override: A/B of two builds
 
 GPT_OK, GPT_E_HIP, GPT_E_NOT_PD, GPT_E_ARG, GPT_E_STATE = 0, -1, -2, -3, -4
 

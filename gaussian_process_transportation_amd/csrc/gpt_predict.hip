@@ -13,6 +13,7 @@
 #include "gpt_common.h"
 #include "gpt_exp.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace gpt {
 
@@ -245,62 +246,64 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlan pl, cons
         // the scratch image is about to be rewritten: drop the L1 lines of it this CU may still hold
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 
-        // this lane's four columns (one per MFMA column tile): scaled query coordinates
-        double q[4][3];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int64_t col = cb * VAR_COLS + 16 * t + lc;
-            const int64_t m = (NCOMP == 1) ? col : (col >> 2);
-            const int64_t mm = (m < M) ? m : (M - 1);
-#pragma unroll
-            for (int d = 0; d < 3; ++d) q[t][d] = (d < D) ? Xq[mm * D + d] * (p.inv_ls[d] * RS2) : 0.0;
-        }
-        double gx[3];                                  // coordinates of the source this wave generates next
-        d2 bl[2];                                      // or the fragments it reloads next
-        auto fetch = [&](const int k4, const bool gen) {
-            if (gen) {
-                const double* xp = Xs + (size_t)(k4 * 4 + lk) * 4;
-                gx[0] = xp[0]; gx[1] = xp[1]; gx[2] = xp[2];
-            } else {
-                bl[0] = bimg[(size_t)k4 * 128]; bl[1] = bimg[(size_t)k4 * 128 + 1];
-            }
-        };
-        auto produce = [&](const int buf, const int k4, const bool gen) {   // B fragments of k-step k4 -> LDS (+ scratch)
-            double* dstl = Bs(buf, k4 % VAR_CH);
-            if (gen) {
-                const double x0 = gx[0] * RS2, x1 = gx[1] * RS2, x2 = gx[2] * RS2;
-                d4 b;
+        double ssq[4] = {0.0, 0.0, 0.0, 0.0}, crs[4] = {0.0, 0.0, 0.0, 0.0};
+
+        // One sweep of i-block ib.  GEN = true (first sweep of the block): B fragments are generated and a copy
+        // is kept in the scratch image; GEN = false: they are reloaded from it.  Two instantiations, so that the
+        // query coordinates and exp temporaries of the generating sweep do not occupy registers in the others.
+        auto sweep = [&](auto gen_tag, const int ib) {
+            constexpr bool GEN = decltype(gen_tag)::value;
+            // this lane's four columns (one per MFMA column tile): scaled query coordinates
+            double q[4][3];
+            if (GEN) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    const double d0 = x0 - q[t][0], d1 = x1 - q[t][1], d2_ = x2 - q[t][2];
-                    double tt = fma(-d0, d0, lnc);
-                    tt = fma(-d1, d1, tt);
-                    tt = fma(-d2_, d2_, tt);
-                    const double kv = exp_tab(tt, Tt);
-                    b[t] = (NCOMP == 1) ? kv : kv * (cbv + cd[0] * d0 + cd[1] * d1 + cd[2] * d2_);
+                    const int64_t col = cb * VAR_COLS + 16 * t + lc;
+                    const int64_t m = (NCOMP == 1) ? col : (col >> 2);
+                    const int64_t mm = (m < M) ? m : (M - 1);
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) q[t][d] = (d < D) ? Xq[mm * D + d] * (p.inv_ls[d] * RS2) : 0.0;
                 }
-                *reinterpret_cast<d4*>(dstl) = b;
-                d2* dst = bimg + (size_t)k4 * 128;
-                dst[0] = d2{b[0], b[1]};
-                dst[1] = d2{b[2], b[3]};
-            } else {
-                *reinterpret_cast<d2*>(dstl) = bl[0];
-                *reinterpret_cast<d2*>(dstl + 2) = bl[1];
             }
-        };
+            double gx[3];                                  // coordinates of the source this wave generates next
+            d2 bl[2];                                      // or the fragments it reloads next
+            auto fetch = [&](const int k4) {
+                if (GEN) {
+                    const double* xp = Xs + (size_t)(k4 * 4 + lk) * 4;
+                    gx[0] = xp[0]; gx[1] = xp[1]; gx[2] = xp[2];
+                } else {
+                    bl[0] = bimg[(size_t)k4 * 128]; bl[1] = bimg[(size_t)k4 * 128 + 1];
+                }
+            };
+            auto produce = [&](const int buf, const int k4) {   // B fragments of k-step k4 -> LDS (+ scratch)
+                double* dstl = Bs(buf, k4 % VAR_CH);
+                if (GEN) {
+                    const double x0 = gx[0] * RS2, x1 = gx[1] * RS2, x2 = gx[2] * RS2;
+                    d4 b;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const double d0 = x0 - q[t][0], d1 = x1 - q[t][1], d2_ = x2 - q[t][2];
+                        double tt = fma(-d0, d0, lnc);
+                        tt = fma(-d1, d1, tt);
+                        tt = fma(-d2_, d2_, tt);
+                        const double kv = exp_tab(tt, Tt);
+                        b[t] = (NCOMP == 1) ? kv : kv * (cbv + cd[0] * d0 + cd[1] * d1 + cd[2] * d2_);
+                    }
+                    *reinterpret_cast<d4*>(dstl) = b;
+                    d2* dst = bimg + (size_t)k4 * 128;
+                    dst[0] = d2{b[0], b[1]};
+                    dst[1] = d2{b[2], b[3]};
+                } else {
+                    *reinterpret_cast<d2*>(dstl) = bl[0];
+                    *reinterpret_cast<d2*>(dstl + 2) = bl[1];
+                }
+            };
 
-        double ssq[4] = {0.0, 0.0, 0.0, 0.0}, crs[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int ib = hi - 1; ib >= lo; --ib) {               // longest sweep first: it covers every source the others need
-            const bool gen = (ib == hi - 1);
-            if (!gen) {     // the scratch image of this block is complete: make it visible before reloading it
-                if (ib == hi - 2) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-                __syncthreads();
-            }
             const size_t S_ib = (size_t)64 * ib * (ib + 1);   // stream index of the first k4-step of this sweep
 #pragma unroll
             for (int j = 0; j < VAR_SUBS; ++j) {              // chunk 0: wave w fills steps w, w+8, w+16, w+24
-                fetch(j * VAR_SUB + w, gen);
-                produce(0, j * VAR_SUB + w, gen);
+                fetch(j * VAR_SUB + w);
+                produce(0, j * VAR_SUB + w);
             }
             d2 a_nxt[2];
             a_nxt[0] = wbase[S_ib * STEP_D2]; a_nxt[1] = wbase[S_ib * STEP_D2 + 64];   // step 0 is active for every group
@@ -316,24 +319,28 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlan pl, cons
             for (int ch = 0; ch < nchunks; ++ch) {
                 const int cur = ch & 1;
                 const bool more = (ch + 1 < nchunks);
+                d4 b_nxt = *reinterpret_cast<const d4*>(Bs(cur, 0));    // B fragments are read one k-step ahead
                 for (int sub = 0; sub < VAR_SUBS; ++sub) {
                     const int k0 = ch * VAR_CH + sub * VAR_SUB;                 // first k-step of this sub-chunk
                     const int kn = (ch + 1) * VAR_CH + sub * VAR_SUB + w;       // the k-step this wave fills meanwhile
-                    if (more) fetch(kn, gen);
+                    if (more) fetch(kn);
                     const bool active = k0 < my_limit;          // my_limit is a multiple of 16: all or nothing
                     auto step = [&](const int s) {
                         const int k4 = k0 + s;
                         const d2 a01 = a_nxt[0], a23 = a_nxt[1];
+                        const d4 b = b_nxt;
                         const size_t Sn = S_ib + ((k4 + 1 < my_limit) ? (k4 + 1) : k4);
                         a_nxt[0] = wbase[Sn * STEP_D2]; a_nxt[1] = wbase[Sn * STEP_D2 + 64];
-                        const d4 b = *reinterpret_cast<const d4*>(Bs(cur, sub * VAR_SUB + s));
+                        const int sn = sub * VAR_SUB + s + 1;
+                        if (sn < VAR_CH) b_nxt = *reinterpret_cast<const d4*>(Bs(cur, sn));
                         GPT_MFMA16(acc, a01, a23, b);
                     };
                     if (active) { step(0); step(1); }
-                    if (more && w < 4) produce(cur ^ 1, kn, gen);
+                    if (more && w < 4) produce(cur ^ 1, kn);
                     if (active) { step(2); step(3); step(4); step(5); }
-                    if (more && w >= 4) produce(cur ^ 1, kn, gen);
+                    if (more && w >= 4) produce(cur ^ 1, kn);
                     if (active) { step(6); step(7); }
+                    else if (sub + 1 < VAR_SUBS) b_nxt = *reinterpret_cast<const d4*>(Bs(cur, (sub + 1) * VAR_SUB));
                 }
                 __syncthreads();
             }
@@ -348,6 +355,16 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlan pl, cons
                         ssq[t] += v * v;
                         if (CROSS) crs[t] += v * __shfl(v, lane & ~3);
                     }
+        };
+
+        sweep(std::true_type{}, hi - 1);                      // longest sweep first: it covers every source the others need
+        if (hi - 2 >= lo) {
+            // every wave's part of the scratch image must have reached L2 before another wave reloads it
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            for (int ib = hi - 2; ib >= lo; --ib) {
+                sweep(std::false_type{}, ib);
+            }
         }
 
         // rows of a column are spread over the 4 lane groups lk = 0..3 and over the 8 waves
