@@ -18,10 +18,11 @@
 namespace gpt {
 
 // ------------------------------------------------------------------------------------------
-template <int QPW>
+// OC = outputs handled by this pass (1..4): only their partial sums are accumulated.
+template <int QPW, int OC>
 __global__ __launch_bounds__(256) void k_mean_jac(KernelParams p, const double* __restrict__ Xs,
                                                   const double* __restrict__ A4, const double* __restrict__ Xq,
-                                                  int64_t M, int o_base, int o_cnt, double* __restrict__ mean,
+                                                  int64_t M, int o_base, double* __restrict__ mean,
                                                   double* __restrict__ J) {
     __shared__ double Tt[256];
     Tt[threadIdx.x] = g_exp2_table[threadIdx.x];
@@ -38,11 +39,11 @@ __global__ __launch_bounds__(256) void k_mean_jac(KernelParams p, const double* 
 #pragma unroll
         for (int d = 0; d < 3; ++d) q[i][d] = (d < D) ? Xq[m * D + d] * (p.inv_ls[d] * RS2) : 0.0;
     }
-    double acc[QPW][4][4];
+    double acc[QPW][OC][4];
 #pragma unroll
     for (int i = 0; i < QPW; ++i)
 #pragma unroll
-        for (int o = 0; o < 4; ++o)
+        for (int o = 0; o < OC; ++o)
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[i][o][e] = 0.0;
 
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(256) void k_mean_jac(KernelParams p, const double* 
             tt = fma(-d2, d2, tt);
             const double kv = exp_tab(tt, Tt);
 #pragma unroll
-            for (int o = 0; o < 4; ++o) {
+            for (int o = 0; o < OC; ++o) {
                 const double t = kv * al[o];
                 acc[i][o][0] += t;
                 acc[i][o][1] += t * d0;
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256) void k_mean_jac(KernelParams p, const double* 
 #pragma unroll
     for (int i = 0; i < QPW; ++i)
 #pragma unroll
-        for (int o = 0; o < 4; ++o)
+        for (int o = 0; o < OC; ++o)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 double v = acc[i][o][e];
@@ -87,8 +88,7 @@ __global__ __launch_bounds__(256) void k_mean_jac(KernelParams p, const double* 
             const int64_t m = m0 + i;
             if (m >= M) break;
 #pragma unroll
-            for (int o = 0; o < 4; ++o) {
-                if (o >= o_cnt) break;
+            for (int o = 0; o < OC; ++o) {
                 const int oo = o_base + o;
                 if (mean) mean[m * O + oo] = acc[i][o][0];
                 if (J) {
@@ -109,8 +109,14 @@ void launch_mean_jac(hipStream_t s, const KernelParams& p, const double* Xs, con
     const int64_t blocks = (waves + 3) / 4;
     for (int ob = 0; ob < p.O; ob += 4) {
         const int cnt = (p.O - ob) < 4 ? (p.O - ob) : 4;
-        hipLaunchKernelGGL(k_mean_jac<QPW>, dim3((unsigned)blocks), dim3(256), 0, s, p, Xs,
-                           A4 + (size_t)(ob / 4) * p.NP * 4, Xq, M, ob, cnt, mean, J);
+        const double* a4 = A4 + (size_t)(ob / 4) * p.NP * 4;
+        const dim3 grid((unsigned)blocks);
+        switch (cnt) {
+            case 1: hipLaunchKernelGGL((k_mean_jac<QPW, 1>), grid, dim3(256), 0, s, p, Xs, a4, Xq, M, ob, mean, J); break;
+            case 2: hipLaunchKernelGGL((k_mean_jac<QPW, 2>), grid, dim3(256), 0, s, p, Xs, a4, Xq, M, ob, mean, J); break;
+            case 3: hipLaunchKernelGGL((k_mean_jac<QPW, 3>), grid, dim3(256), 0, s, p, Xs, a4, Xq, M, ob, mean, J); break;
+            default: hipLaunchKernelGGL((k_mean_jac<QPW, 4>), grid, dim3(256), 0, s, p, Xs, a4, Xq, M, ob, mean, J);
+        }
     }
 }
 
