@@ -28,6 +28,7 @@ SIGNATURES = {
     "gpt_set_stream": (C.c_int, [_vp, _vp]),
     "gpt_synchronize": (C.c_int, [_vp]),
     "gpt_fit": (C.c_int, [_vp, _dp, _dp, _i64, C.c_int, C.c_int, _dp, C.c_int, C.c_double, C.c_double, C.c_double]),
+    "gpt_fit_kernel": (C.c_int, [_vp, _dp, _dp, _i64, C.c_int, C.c_int, _dp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int]),
     "gpt_predict": (C.c_int, [_vp, _dp, _i64, _dp, _dp]),
     "gpt_derivative": (C.c_int, [_vp, _dp, _i64, _dp, _dp]),
     "gpt_dvariance": (C.c_int, [_vp, _dp, _i64, _dp]),
@@ -150,15 +151,16 @@ class Handle:
             pass
 
     # ---- fit / export
-    def fit(self, X, Y, length_scale, constant_value, noise_level, alpha):
+    def fit(self, X, Y, length_scale, constant_value, noise_level, alpha, kernel_type=0):
+        """kernel_type: 0 RBF, 1/2/3 Matern nu = 0.5 / 1.5 / 2.5 (GPT_KERNEL_* of include/gpt_hip.h)."""
         X = as_f64(X, 2)
         Y = as_f64(Y, 2)
         ls = as_f64(np.atleast_1d(length_scale), 1)
         N, D = X.shape
         if Y.shape[0] != N:
             raise ValueError("X and Y have different numbers of rows")
-        check(self.lib.gpt_fit(self._h, dptr(X), dptr(Y), N, D, Y.shape[1], dptr(ls), ls.size,
-                               float(constant_value), float(noise_level), float(alpha)), "gpt_fit")
+        check(self.lib.gpt_fit_kernel(self._h, dptr(X), dptr(Y), N, D, Y.shape[1], dptr(ls), ls.size,
+                                      float(constant_value), float(noise_level), float(alpha), int(kernel_type)), "gpt_fit")
 
     def info(self):
         N, NP, D, O = _i64(), _i64(), C.c_int(), C.c_int()

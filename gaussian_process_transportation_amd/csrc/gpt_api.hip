@@ -152,6 +152,7 @@ void fill_params(gpt_handle* h, const double* hdr) {
     p.N = (int)hdr[1]; p.NP = (int)hdr[2]; p.D = (int)hdr[3]; p.O = (int)hdr[4];
     p.c = hdr[5]; p.noise = hdr[6];
     p.lnc = std::log(hdr[5]);
+    p.ktype = (int)hdr[13];
     h->jitter = hdr[7];
     h->n_ls = (int)hdr[11];
     for (int d = 0; d < 3; ++d) {
@@ -226,7 +227,14 @@ int gpt_synchronize(gpt_handle* h) {
 int gpt_fit(gpt_handle* h, const double* X, const double* Y, int64_t N, int D, int O,
             const double* length_scale, int n_ls, double constant_value, double noise_level,
             double alpha_jitter) {
+    return gpt_fit_kernel(h, X, Y, N, D, O, length_scale, n_ls, constant_value, noise_level, alpha_jitter, GPT_KERNEL_RBF);
+}
+
+int gpt_fit_kernel(gpt_handle* h, const double* X, const double* Y, int64_t N, int D, int O,
+                   const double* length_scale, int n_ls, double constant_value, double noise_level,
+                   double alpha_jitter, int kernel_type) {
     if (!h || !X || !Y || !length_scale) return fail(GPT_E_ARG, "gpt_fit: NULL argument");
+    if (kernel_type < GPT_KERNEL_RBF || kernel_type > GPT_KERNEL_MATERN52) return fail(GPT_E_ARG, "gpt_fit: unknown kernel_type");
     if (N < 1 || N > (1 << 20)) return fail(GPT_E_ARG, "gpt_fit: N out of range");
     if (D < 1 || D > 3) return fail(GPT_E_ARG, "gpt_fit: D must be 1, 2 or 3");
     if (O < 1) return fail(GPT_E_ARG, "gpt_fit: O must be >= 1");
@@ -248,7 +256,7 @@ int gpt_fit(gpt_handle* h, const double* X, const double* Y, int64_t N, int D, i
     hdr[0] = MAGIC; hdr[1] = (double)N; hdr[2] = (double)NP; hdr[3] = D; hdr[4] = O;
     hdr[5] = constant_value; hdr[6] = noise_level; hdr[7] = alpha_jitter;
     for (int d = 0; d < 3; ++d) hdr[8 + d] = (d < D) ? length_scale[n_ls == 1 ? 0 : d] : 1.0;
-    hdr[11] = n_ls; hdr[12] = l.npass;
+    hdr[11] = n_ls; hdr[12] = l.npass; hdr[13] = kernel_type;
     fill_params(h, hdr.data());
     std::vector<double> xs((size_t)NP * 4, 0.0), y4((size_t)l.npass * NP * 4, 0.0);
     for (int64_t i = 0; i < N; ++i) {
@@ -265,7 +273,7 @@ int gpt_fit(gpt_handle* h, const double* X, const double* Y, int64_t N, int D, i
     HIPCHK(hipEventRecord(h->ev[0], s));
     HIPCHK(hipMemsetAsync(h->dinfo, 0, sizeof(int), s));
     HIPCHK(hipMemsetAsync(h->dW, 0, (size_t)NP * NP * sizeof(double), s));
-    launch_gram(s, h->dXs(), (int)N, NP, constant_value, noise_level + alpha_jitter, h->dK);
+    launch_gram(s, h->dXs(), (int)N, NP, kernel_type, constant_value, noise_level + alpha_jitter, h->dK);
     HIPCHK(hipEventRecord(h->ev[1], s));
     launch_potrf(s, h->dK, h->dW, NP, h->dinfo);
     HIPCHK(hipEventRecord(h->ev[2], s));
@@ -304,6 +312,8 @@ int gpt_predict_all_dev(gpt_handle* h, const double* Xq, int64_t M, double* mean
     if (!h->committed) return fail(GPT_E_STATE, "predict: model is not fitted");
     if (M < 0 || (M > 0 && !Xq)) return fail(GPT_E_ARG, "predict: bad query buffer");
     if (M == 0) return GPT_OK;
+    if ((J || Jvar || dvar) && h->p.ktype != GPT_KERNEL_RBF)
+        return fail(GPT_E_ARG, "derivative / Jacobian variance / d variance are defined for the RBF kernel only");
     if (int rc = set_device(h)) return rc;
     hipStream_t s = h->stream;
     const bool prof = h->profiling;
@@ -489,7 +499,7 @@ int gpt_lml_gradient(gpt_handle* h, double* lml, double* grad) {
     }
     h->have_factor_ws = false;                                   // L is gone: gpt_export(L) needs a new gpt_fit
     launch_kinv(s, h->dW, (int)NP, h->dK);
-    launch_lml_terms(s, h->dXs(), h->dA4(), h->lay.npass, h->dK, (int)N, (int)NP, O, h->p.c, h->slab, h->dscal);
+    launch_lml_terms(s, h->dXs(), h->dA4(), h->lay.npass, h->dK, (int)N, (int)NP, O, h->p.ktype, h->p.c, h->slab, h->dscal);
     HIPCHK(hipGetLastError());
     double S[5];
     HIPCHK(hipMemcpyAsync(S, h->dscal, sizeof S, hipMemcpyDeviceToHost, s));

@@ -33,11 +33,12 @@ struct KernelParams {
     int O;               // outputs
     int N;               // source points
     int NP;              // padded source points
+    int ktype;           // 0 RBF, 1/2/3 Matern nu = 1/2, 3/2, 5/2 (gpt_exp.h)
 };
 
 // ---- launchers (defined in the .hip files) --------------------------------------------
 // fit
-void launch_gram(hipStream_t s, const double* Xs, int N, int NP, double c, double diag_add, double* K);
+void launch_gram(hipStream_t s, const double* Xs, int N, int NP, int ktype, double c, double diag_add, double* K);
 void launch_potrf(hipStream_t s, double* K, double* W, int NP, int* info);
 void launch_trinv(hipStream_t s, const double* L, double* W, int NP, double* scratch /* >= NP*NP/4 doubles */);
 void launch_alpha(hipStream_t s, const double* W, const double* Y4, int N, int NP, double* tmp4, double* A4);
@@ -47,7 +48,7 @@ void launch_kinv(hipStream_t s, const double* W, int NP, double* Kout);
 void launch_cov(hipStream_t s, const KernelParams& p, const double* Xs, const double* W, const double* Xq_dev, int64_t M,
                 int Mp, double* KsT /* NP*Mp */, double* V /* NP*Mp */, double* VtV /* Mp*Mp */, double* cov_dev /* M*M */);
 void launch_lml_terms(hipStream_t s, const double* Xs, const double* A4, int npass, const double* Kinv, int N, int NP,
-                      int O, double c, double* partial /* (NP/64)^2*8 doubles */, double* out /* 5 doubles */);
+                      int O, int ktype, double c, double* partial /* (NP/64)^2*8 doubles */, double* out /* 5 doubles */);
 // predict
 void launch_mean_jac(hipStream_t s, const KernelParams& p, const double* Xs, const double* A4,
                      const double* Xq, int64_t M, double* mean, double* J);

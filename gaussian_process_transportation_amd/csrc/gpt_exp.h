@@ -26,4 +26,30 @@ __device__ __forceinline__ double exp_tab(double t, const double* __restrict__ T
     return ldexp(tj * pz, ni >> 8);
 }
 
+// Stationary kernels of the path (sklearn/gaussian_process/kernels.py: RBF 1553-1565, Matern 1717-1745):
+//   KT 0: RBF  exp(-r^2/2)      KT 1: Matern 1/2  exp(-r)
+//   KT 2: Matern 3/2  (1 + sqrt3 r) exp(-sqrt3 r)      KT 3: Matern 5/2  (1 + sqrt5 r + 5/3 r^2) exp(-sqrt5 r)
+// with r = |(x - x')/l|.  kernel_libm: c * k(r^2) with the device libm (fit-side kernels).
+// kernel_tab: exp(lnc) * k, from h = r^2/2, with the table exp (prediction kernels).
+constexpr int KT_RBF = 0, KT_MATERN12 = 1, KT_MATERN32 = 2, KT_MATERN52 = 3;
+
+__device__ __forceinline__ double kernel_libm(const int kt, const double c, const double r2) {
+    if (kt == KT_RBF) return c * exp(-0.5 * r2);
+    const double r = sqrt(r2);
+    if (kt == KT_MATERN12) return c * exp(-r);
+    if (kt == KT_MATERN32) { const double t = 1.7320508075688772 * r; return c * (1.0 + t) * exp(-t); }
+    const double t = 2.23606797749979 * r;
+    return c * (1.0 + t + t * t * (1.0 / 3.0)) * exp(-t);
+}
+
+template <int KT>
+__device__ __forceinline__ double kernel_tab(const double h, const double lnc, const double* __restrict__ T) {
+    if (KT == KT_RBF) return exp_tab(lnc - h, T);
+    const double r = sqrt(h + h);
+    if (KT == KT_MATERN12) return exp_tab(lnc - r, T);
+    if (KT == KT_MATERN32) { const double t = 1.7320508075688772 * r; return (1.0 + t) * exp_tab(lnc - t, T); }
+    const double t = 2.23606797749979 * r;
+    return (1.0 + t + t * t * (1.0 / 3.0)) * exp_tab(lnc - t, T);
+}
+
 }  // namespace gpt

@@ -7,6 +7,7 @@
 // the diagonal, cholesky, cho_solve) and models/gaussian_process.py:42-43 (explicit K^-1, here
 // kept as its triangular factor W = L^-1 so that k^T K^-1 k = |W k|^2).
 #include "gpt_common.h"
+#include "gpt_exp.h"
 
 namespace gpt {
 
@@ -15,7 +16,7 @@ namespace gpt {
 // block lower triangle; padded rows/cols get the identity so the factorisation stays PD.
 // HBM-write bound: one 64x64 tile per workgroup, 16 consecutive doubles per thread.
 // =====================================================================================
-__global__ __launch_bounds__(256) void k_gram(const double* __restrict__ Xs, int N, int NP, double c,
+__global__ __launch_bounds__(256) void k_gram(const double* __restrict__ Xs, int N, int NP, int ktype, double c,
                                               double diag_add, double* __restrict__ K) {
     const int bi = blockIdx.y, bj = blockIdx.x;
     if (bj > bi) return;
@@ -41,8 +42,8 @@ __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ Xs, int
             const int cc = cs + u + e;
             const int j = bj * 64 + cc;
             const double d0 = a0 - xj[cc][0], d1 = a1 - xj[cc][1], d2 = a2 - xj[cc][2];
-            double val = c * exp(-0.5 * (d0 * d0 + d1 * d1 + d2 * d2));
-            if (i == j) val += diag_add;
+            double val = kernel_libm(ktype, c, d0 * d0 + d1 * d1 + d2 * d2);
+            if (i == j) val = c + diag_add;            // k(0) = 1 exactly (kernels.py:1562)
             if (i >= N || j >= N) val = (i == j) ? 1.0 : 0.0;
             v[e] = val;
         }
@@ -50,9 +51,9 @@ __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ Xs, int
     }
 }
 
-void launch_gram(hipStream_t s, const double* Xs, int N, int NP, double c, double diag_add, double* K) {
+void launch_gram(hipStream_t s, const double* Xs, int N, int NP, int ktype, double c, double diag_add, double* K) {
     dim3 grid(NP / 64, NP / 64);
-    hipLaunchKernelGGL(k_gram, grid, dim3(256), 0, s, Xs, N, NP, c, diag_add, K);
+    hipLaunchKernelGGL(k_gram, grid, dim3(256), 0, s, Xs, N, NP, ktype, c, diag_add, K);
 }
 
 // =====================================================================================
@@ -459,7 +460,7 @@ void launch_kinv(hipStream_t s, const double* W, int NP, double* Kout) {
 }
 
 __global__ __launch_bounds__(256) void k_lml_terms(const double* __restrict__ Xs, const double* __restrict__ A4, int npass,
-                                                   const double* __restrict__ Kinv, int N, int NP, int O, double c,
+                                                   const double* __restrict__ Kinv, int N, int NP, int O, int ktype, double c,
                                                    double* __restrict__ partial /* [blocks][8] */) {
     const int bi = blockIdx.y, bj = blockIdx.x;
     const int t = threadIdx.x;
@@ -481,9 +482,21 @@ __global__ __launch_bounds__(256) void k_lml_terms(const double* __restrict__ Xs
                 const double inner = aa - (double)O * Kinv[(size_t)i * NP + j];
                 const double wgt = (i == j) ? 1.0 : 2.0;
                 const double d0 = xi0 - Xs[(size_t)j * 4], d1 = xi1 - Xs[(size_t)j * 4 + 1], d2 = xi2 - Xs[(size_t)j * 4 + 2];
-                const double kr = c * exp(-0.5 * (d0 * d0 + d1 * d1 + d2 * d2));
-                const double v = wgt * inner * kr;
-                S[0] += v; S[1] += v * d0 * d0; S[2] += v * d1 * d1; S[3] += v * d2 * d2;
+                const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
+                const double kr = kernel_libm(ktype, c, r2);
+                // dK/dlog l_d = gk * (xs_id - xs_jd)^2  (kernels.py: RBF 1568-1580, Matern 1747-1778)
+                double gk;
+                if (ktype == KT_RBF) gk = kr;
+                else {
+                    const double r = sqrt(r2);
+                    if (ktype == KT_MATERN12) gk = (r > 0.0) ? kr / r : 0.0;
+                    else if (ktype == KT_MATERN32) gk = 3.0 * c * exp(-1.7320508075688772 * r);
+                    else { const double t = 2.23606797749979 * r; gk = (5.0 / 3.0) * c * (t + 1.0) * exp(-t); }
+                }
+                const double wi = wgt * inner;
+                S[0] += wi * kr;
+                const double v = wi * gk;
+                S[1] += v * d0 * d0; S[2] += v * d1 * d1; S[3] += v * d2 * d2;
                 if (i == j) S[4] += inner;
             }
         }
@@ -521,9 +534,9 @@ __global__ __launch_bounds__(256) void k_sum_partials(const double* __restrict__
 
 // partial: (NP/64)^2 * 8 doubles of scratch; out: 5 doubles
 void launch_lml_terms(hipStream_t s, const double* Xs, const double* A4, int npass, const double* Kinv, int N, int NP,
-                      int O, double c, double* partial, double* out) {
+                      int O, int ktype, double c, double* partial, double* out) {
     const int nb = NP / 64;
-    hipLaunchKernelGGL(k_lml_terms, dim3(nb, nb), dim3(256), 0, s, Xs, A4, npass, Kinv, N, NP, O, c, partial);
+    hipLaunchKernelGGL(k_lml_terms, dim3(nb, nb), dim3(256), 0, s, Xs, A4, npass, Kinv, N, NP, O, ktype, c, partial);
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, partial, nb * nb, out);
 }
 
@@ -532,7 +545,7 @@ void launch_lml_terms(hipStream_t s, const double* Xs, const double* A4, int npa
 // where V = L \ K*^T).  Small-M path (sampling, return_cov): K*^T and V are materialised (NP x Mp).
 // =====================================================================================
 __global__ __launch_bounds__(256) void k_cross_t(const double* __restrict__ Xs, const double* __restrict__ Xq, int N, int NP,
-                                                 int64_t M, int Mp, int D, double c, double il0, double il1, double il2,
+                                                 int64_t M, int Mp, int D, int ktype, double c, double il0, double il1, double il2,
                                                  double* __restrict__ KsT /* [NP][Mp] */) {
     const int t = threadIdx.x;
     const int n = blockIdx.y * 64 + (t >> 2);
@@ -546,13 +559,13 @@ __global__ __launch_bounds__(256) void k_cross_t(const double* __restrict__ Xs, 
             const double q1 = D > 1 ? Xq[(size_t)m * D + 1] * il1 : 0.0;
             const double q2 = D > 2 ? Xq[(size_t)m * D + 2] * il2 : 0.0;
             const double d0 = x0 - q0, d1 = x1 - q1, d2 = x2 - q2;
-            v = c * exp(-0.5 * (d0 * d0 + d1 * d1 + d2 * d2));
+            v = kernel_libm(ktype, c, d0 * d0 + d1 * d1 + d2 * d2);
         }
         KsT[(size_t)n * Mp + m] = v;
     }
 }
 
-__global__ __launch_bounds__(256) void k_cov_finish(const double* __restrict__ Xq, int64_t M, int Mp, int D, double c, double noise,
+__global__ __launch_bounds__(256) void k_cov_finish(const double* __restrict__ Xq, int64_t M, int Mp, int D, int ktype, double c, double noise,
                                                     double il0, double il1, double il2, const double* __restrict__ VtV,
                                                     double* __restrict__ cov /* [M][M] */) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -561,7 +574,7 @@ __global__ __launch_bounds__(256) void k_cov_finish(const double* __restrict__ X
     double d2 = 0.0;
     const double il[3] = {il0, il1, il2};
     for (int d = 0; d < D; ++d) { const double df = (Xq[i * D + d] - Xq[j * D + d]) * il[d]; d2 += df * df; }
-    double v = (i == j) ? (c + noise) : c * exp(-0.5 * d2);      // RBF diagonal is exactly 1 (kernels.py:1562)
+    double v = (i == j) ? (c + noise) : kernel_libm(ktype, c, d2);      // k(0) = 1 exactly (kernels.py:1562)
     cov[e] = v - VtV[(size_t)i * Mp + j];
 }
 
@@ -569,7 +582,7 @@ __global__ __launch_bounds__(256) void k_cov_finish(const double* __restrict__ X
 void launch_cov(hipStream_t s, const KernelParams& p, const double* Xs, const double* W, const double* Xq_dev, int64_t M,
                 int Mp, double* KsT, double* V, double* VtV, double* cov_dev) {
     const int NP = p.NP;
-    hipLaunchKernelGGL(k_cross_t, dim3(Mp / 64, NP / 64), dim3(256), 0, s, Xs, Xq_dev, p.N, NP, M, Mp, p.D, p.c,
+    hipLaunchKernelGGL(k_cross_t, dim3(Mp / 64, NP / 64), dim3(256), 0, s, Xs, Xq_dev, p.N, NP, M, Mp, p.D, p.ktype, p.c,
                        p.inv_ls[0], p.inv_ls[1], p.inv_ls[2], KsT);
     GemmArgs a{};
     a.A = W; a.lda = NP; a.B = KsT; a.ldb = Mp; a.C = V; a.ldc = Mp;
@@ -582,7 +595,7 @@ void launch_cov(hipStream_t s, const KernelParams& p, const double* Xs, const do
     b.alpha = 1.0; b.beta = 0.0;
     launch_gemm<false, true>(s, b);
     const int64_t tot = M * M;
-    hipLaunchKernelGGL(k_cov_finish, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, Xq_dev, M, Mp, p.D, p.c, p.noise,
+    hipLaunchKernelGGL(k_cov_finish, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, Xq_dev, M, Mp, p.D, p.ktype, p.c, p.noise,
                        p.inv_ls[0], p.inv_ls[1], p.inv_ls[2], VtV, cov_dev);
 }
 

@@ -19,7 +19,7 @@ namespace gpt {
 
 // ------------------------------------------------------------------------------------------
 // OC = outputs handled by this pass (1..4): only their partial sums are accumulated.
-template <int QPW, int OC>
+template <int QPW, int OC, int KT>
 __global__ __launch_bounds__(256) void k_mean_jac(KernelParams p, const double* __restrict__ Xs,
                                                   const double* __restrict__ A4, const double* __restrict__ Xq,
                                                   int64_t M, int o_base, double* __restrict__ mean,
@@ -55,10 +55,10 @@ __global__ __launch_bounds__(256) void k_mean_jac(KernelParams p, const double* 
 #pragma unroll
         for (int i = 0; i < QPW; ++i) {
             const double d0 = x0 - q[i][0], d1 = x1 - q[i][1], d2 = x2 - q[i][2];
-            double tt = fma(-d0, d0, lnc);
-            tt = fma(-d1, d1, tt);
-            tt = fma(-d2, d2, tt);
-            const double kv = exp_tab(tt, Tt);
+            double hh = d0 * d0;
+            hh = fma(d1, d1, hh);
+            hh = fma(d2, d2, hh);
+            const double kv = kernel_tab<KT>(hh, lnc, Tt);
 #pragma unroll
             for (int o = 0; o < OC; ++o) {
                 const double t = kv * al[o];
@@ -111,12 +111,22 @@ void launch_mean_jac(hipStream_t s, const KernelParams& p, const double* Xs, con
         const int cnt = (p.O - ob) < 4 ? (p.O - ob) : 4;
         const double* a4 = A4 + (size_t)(ob / 4) * p.NP * 4;
         const dim3 grid((unsigned)blocks);
-        switch (cnt) {
-            case 1: hipLaunchKernelGGL((k_mean_jac<QPW, 1>), grid, dim3(256), 0, s, p, Xs, a4, Xq, M, ob, mean, J); break;
-            case 2: hipLaunchKernelGGL((k_mean_jac<QPW, 2>), grid, dim3(256), 0, s, p, Xs, a4, Xq, M, ob, mean, J); break;
-            case 3: hipLaunchKernelGGL((k_mean_jac<QPW, 3>), grid, dim3(256), 0, s, p, Xs, a4, Xq, M, ob, mean, J); break;
-            default: hipLaunchKernelGGL((k_mean_jac<QPW, 4>), grid, dim3(256), 0, s, p, Xs, a4, Xq, M, ob, mean, J);
+#define GPT_MJ(OC_, KT_) hipLaunchKernelGGL((k_mean_jac<QPW, OC_, KT_>), grid, dim3(256), 0, s, p, Xs, a4, Xq, M, ob, mean, J)
+#define GPT_MJ_K(OC_)                                     \
+        switch (p.ktype) {                                 \
+            case KT_MATERN12: GPT_MJ(OC_, KT_MATERN12); break; \
+            case KT_MATERN32: GPT_MJ(OC_, KT_MATERN32); break; \
+            case KT_MATERN52: GPT_MJ(OC_, KT_MATERN52); break; \
+            default: GPT_MJ(OC_, KT_RBF);                  \
         }
+        switch (cnt) {
+            case 1: GPT_MJ_K(1); break;
+            case 2: GPT_MJ_K(2); break;
+            case 3: GPT_MJ_K(3); break;
+            default: GPT_MJ_K(4);
+        }
+#undef GPT_MJ_K
+#undef GPT_MJ
     }
 }
 
@@ -202,7 +212,7 @@ __host__ __device__ inline void var_boundary(const VarPlan& pl, int p, int64_t& 
         acc[3][t_] = __builtin_amdgcn_mfma_f64_16x16x4f64((a23)[1], (b)[t_], acc[3][t_], 0, 0, 0); \
     }
 
-template <int NCOMP, bool CROSS>
+template <int NCOMP, bool CROSS, int KT>
 __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlan pl, const double* __restrict__ Xs,
                                                 const double* __restrict__ Wf, const double* __restrict__ Xq,
                                                 int64_t M, double* __restrict__ slab, double* __restrict__ bscratch) {
@@ -289,10 +299,10 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlan pl, cons
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const double d0 = x0 - q[t][0], d1 = x1 - q[t][1], d2_ = x2 - q[t][2];
-                        double tt = fma(-d0, d0, lnc);
-                        tt = fma(-d1, d1, tt);
-                        tt = fma(-d2_, d2_, tt);
-                        const double kv = exp_tab(tt, Tt);
+                        double hh = d0 * d0;
+                        hh = fma(d1, d1, hh);
+                        hh = fma(d2_, d2_, hh);
+                        const double kv = kernel_tab<KT>(hh, lnc, Tt);
                         b[t] = (NCOMP == 1) ? kv : kv * (cbv + cd[0] * d0 + cd[1] * d1 + cd[2] * d2_);
                     }
                     *reinterpret_cast<d4*>(dstl) = b;
@@ -481,18 +491,24 @@ void launch_var(hipStream_t s, const KernelParams& p, const double* Xs, const do
     const VarPlan pl = make_plan(p, M, ncomp);
     static bool attr_set = false;
     if (!attr_set) {      // 128 KiB of dynamic LDS per workgroup
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_var<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)VAR_LDS_BYTES);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_var<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)VAR_LDS_BYTES);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_var<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)VAR_LDS_BYTES);
+        const void* fns[] = {reinterpret_cast<const void*>(k_var<1, false, KT_RBF>), reinterpret_cast<const void*>(k_var<4, true, KT_RBF>),
+                             reinterpret_cast<const void*>(k_var<4, false, KT_RBF>), reinterpret_cast<const void*>(k_var<1, false, KT_MATERN12>),
+                             reinterpret_cast<const void*>(k_var<1, false, KT_MATERN32>), reinterpret_cast<const void*>(k_var<1, false, KT_MATERN52>)};
+        for (const void* f : fns) hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VAR_LDS_BYTES);
         attr_set = true;
     }
     const dim3 grid((unsigned)pl.P), fgrid((unsigned)pl.ncb);
     if (ncomp == 1) {
-        hipLaunchKernelGGL((k_var<1, false>), grid, dim3(512), VAR_LDS_BYTES, s, p, pl, Xs, Wf, Xq, M, slab, bscratch);
+        switch (p.ktype) {
+            case KT_MATERN12: hipLaunchKernelGGL((k_var<1, false, KT_MATERN12>), grid, dim3(512), VAR_LDS_BYTES, s, p, pl, Xs, Wf, Xq, M, slab, bscratch); break;
+            case KT_MATERN32: hipLaunchKernelGGL((k_var<1, false, KT_MATERN32>), grid, dim3(512), VAR_LDS_BYTES, s, p, pl, Xs, Wf, Xq, M, slab, bscratch); break;
+            case KT_MATERN52: hipLaunchKernelGGL((k_var<1, false, KT_MATERN52>), grid, dim3(512), VAR_LDS_BYTES, s, p, pl, Xs, Wf, Xq, M, slab, bscratch); break;
+            default: hipLaunchKernelGGL((k_var<1, false, KT_RBF>), grid, dim3(512), VAR_LDS_BYTES, s, p, pl, Xs, Wf, Xq, M, slab, bscratch);
+        }
         hipLaunchKernelGGL((k_var_finalize<1>), fgrid, dim3(64), 0, s, p, pl, slab, M, var, Jvar, dvar);
-    } else {
-        if (dvar) hipLaunchKernelGGL((k_var<4, true>), grid, dim3(512), VAR_LDS_BYTES, s, p, pl, Xs, Wf, Xq, M, slab, bscratch);
-        else hipLaunchKernelGGL((k_var<4, false>), grid, dim3(512), VAR_LDS_BYTES, s, p, pl, Xs, Wf, Xq, M, slab, bscratch);
+    } else {      // Jacobian variance / d var: RBF only (the API refuses other kernels)
+        if (dvar) hipLaunchKernelGGL((k_var<4, true, KT_RBF>), grid, dim3(512), VAR_LDS_BYTES, s, p, pl, Xs, Wf, Xq, M, slab, bscratch);
+        else hipLaunchKernelGGL((k_var<4, false, KT_RBF>), grid, dim3(512), VAR_LDS_BYTES, s, p, pl, Xs, Wf, Xq, M, slab, bscratch);
         hipLaunchKernelGGL((k_var_finalize<4>), fgrid, dim3(64), 0, s, p, pl, slab, M, var, Jvar, dvar);
     }
 }

@@ -25,10 +25,22 @@ def kernel_hyperparameters(kernel):
     except (AttributeError, KeyError) as e:
         raise ValueError("kernel must be ConstantKernel * RBF + WhiteKernel (as the reference's parameter "
                          "names k1__k1__constant_value / k1__k2__length_scale / k2__noise_level require)") from e
-    stationary = type(p.get("k1__k2", None)).__name__
-    if stationary != "RBF":
-        raise NotImplementedError(f"only the RBF kernel runs on the GPU path, got {stationary}")
     return float(c), np.atleast_1d(np.asarray(ls, dtype=np.float64)), float(noise)
+
+
+def kernel_type(kernel):
+    """GPT_KERNEL_* code of the stationary factor: RBF, or Matern with nu in {0.5, 1.5, 2.5, inf}."""
+    k = kernel.get_params().get("k1__k2", None)
+    name = type(k).__name__
+    if name == "RBF":
+        return 0
+    if name == "Matern":
+        nu = float(k.nu)
+        codes = {0.5: 1, 1.5: 2, 2.5: 3, float("inf"): 0}
+        if nu in codes:
+            return codes[nu]
+        raise NotImplementedError(f"Matern(nu={nu}) is not on the GPU path (nu must be 0.5, 1.5, 2.5 or inf)")
+    raise NotImplementedError(f"only RBF and Matern kernels run on the GPU path, got {name}")
 
 
 class _FittedView:
@@ -99,13 +111,14 @@ class GaussianProcess:
             raise ValueError(f"The number of targets seen in `y` is different from the parameter `n_targets`. "
                              f"Got {self.n_outputs} != {self.n_targets}.")
         c, ls, noise = kernel_hyperparameters(self._kernel_in)
+        self._ktype = kernel_type(self._kernel_in)
         lml = None
         if self.optimizer is not None:
             from .hyperopt import optimize_hyperparameters
             c, ls, noise, lml = optimize_hyperparameters(self, c, ls, noise)
         if self._handle is None:
             self._handle = _lib.Handle(self.device)
-        self._handle.fit(self.X, self.Y, ls, c, noise, self.alpha)
+        self._handle.fit(self.X, self.Y, ls, c, noise, self.alpha, self._ktype)
         self._K_inv = None
         # fitted kernel object with the reference's attribute protocol (:38-41)
         fitted = copy.deepcopy(self._kernel_in)
@@ -133,6 +146,11 @@ class GaussianProcess:
             W = self._handle.export_inverse_factor()
             self._K_inv = W.T @ W
         return self._K_inv
+
+    def _require_rbf(self, what):
+        if self._ktype != 0:
+            raise NotImplementedError(f"{what}() implements the RBF formulas of the reference (gaussian_process.py:63-126); "
+                                      "the reference silently applies them to any kernel, this path refuses")
 
     def _require_fit(self):
         if self._handle is None:
@@ -175,6 +193,7 @@ class GaussianProcess:
     def derivative(self, x, return_var=False):
         """(:63-102)  J (M,O,D) = d mean_o / d x_d; with return_var also its variance, tiled over outputs."""
         self._require_fit()
+        self._require_rbf("derivative")
         out = self._handle.predict_all(x, J=True, Jvar=bool(return_var))
         if not return_var:
             return out["J"]
@@ -184,10 +203,12 @@ class GaussianProcess:
     def derivative_of_variance(self, x):
         """(:104-126)  (D, M) array of d var / d x_d."""
         self._require_fit()
+        self._require_rbf("derivative_of_variance")
         return self._handle.predict_all(x, dvar=True)["dvar"]
 
     # ------------------------------------------------------------------ fused metric path
     def posterior(self, x, jacobian_variance=False):
         """One call for mean (M,O), raw variance (M,), Jacobian (M,O,D) [and Jacobian variance (M,D)]."""
         self._require_fit()
+        self._require_rbf("posterior")
         return self._handle.predict_all(x, mean=True, var=True, J=True, Jvar=bool(jacobian_variance))

@@ -59,7 +59,7 @@ def optimize_hyperparameters(gp, c0, ls0, noise0):
     def objective(theta):
         c, ls, noise = _unpack(kernel, theta)
         try:
-            h.fit(X, Y, ls, c, noise, jitter)
+            h.fit(X, Y, ls, c, noise, jitter, gp._ktype)
             lml, grad = h.lml_gradient(n_ls)
         except np.linalg.LinAlgError:                      # _gpr.py:587-590: -inf LML, zero gradient
             return np.inf, np.zeros_like(theta)

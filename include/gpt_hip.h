@@ -61,6 +61,18 @@ int gpt_fit(gpt_handle* h, const double* X, const double* Y, int64_t N, int D, i
             const double* length_scale, int n_ls, double constant_value, double noise_level,
             double alpha_jitter);
 
+/* The same for `ConstantKernel * Matern(nu) + WhiteKernel` (sklearn/gaussian_process/kernels.py:1717-1778), the
+ * kernel the reference's examples use for their dynamics GP (example/2D/surface_generalization.py:49,
+ * example/3D/surface_generalization_3D.py:42).  gpt_fit == kernel_type GPT_KERNEL_RBF.  Derivative entry points
+ * stay RBF-only (the reference's derivative formulas, gaussian_process.py:63-126, are RBF formulas). */
+#define GPT_KERNEL_RBF 0
+#define GPT_KERNEL_MATERN12 1
+#define GPT_KERNEL_MATERN32 2
+#define GPT_KERNEL_MATERN52 3
+int gpt_fit_kernel(gpt_handle* h, const double* X, const double* Y, int64_t N, int D, int O,
+                   const double* length_scale, int n_ls, double constant_value, double noise_level,
+                   double alpha_jitter, int kernel_type);
+
 /* predict — replaces GaussianProcess.predict (gaussian_process.py:46-55 -> sklearn/_gpr.py:441-494).
  * mean (M,O); var (M,) = max(c + noise_level - |L^-1 k*|^2, 0) (the caller applies sqrt, the
  * tiling over O and the reference's `- sqrt(noise_level)` quirk).  var may be NULL. Host memory. */

@@ -24,41 +24,63 @@ from scipy.spatial.distance import cdist, pdist, squareform
 
 
 # --------------------------------------------------------------------------- kernels
-def rbf_gram(X, Y=None, length_scale=1.0):
-    """exp(-0.5 * ||(x-y)/l||^2).  sklearn: kernels.py:1553-1565 (RBF.__call__).
+KINDS = ("rbf", "matern12", "matern32", "matern52")
 
-    X-only form goes through pdist + squareform with the diagonal forced to 1,
-    the two-argument form through cdist, both on inputs divided by length_scale
-    (scalar or (D,))."""
+
+def _shape(kind, r):
+    """k(r) for r = |(x-y)/l|.  sklearn: kernels.py RBF 1553-1565, Matern 1717-1745 (nu = 0.5, 1.5, 2.5)."""
+    if kind == "rbf":
+        return np.exp(-0.5 * r * r)
+    if kind == "matern12":
+        return np.exp(-r)
+    if kind == "matern32":
+        t = r * np.sqrt(3.0)
+        return (1.0 + t) * np.exp(-t)
+    if kind == "matern52":
+        t = r * np.sqrt(5.0)
+        return (1.0 + t + t ** 2 / 3.0) * np.exp(-t)
+    raise ValueError(kind)
+
+
+def rbf_gram(X, Y=None, length_scale=1.0, kind="rbf"):
+    """Stationary part of the kernel.  RBF: exp(-0.5 ||(x-y)/l||^2), sklearn kernels.py:1553-1565: the
+    X-only form goes through pdist + squareform with the diagonal forced to 1, the two-argument form
+    through cdist, both on inputs divided by length_scale (scalar or (D,)).  Matern (kernels.py:1717-1745)
+    does the same with the euclidean metric."""
     ls = np.asarray(length_scale, dtype=np.float64)
+    if kind == "rbf":
+        if Y is None:
+            d = pdist(X / ls, metric="sqeuclidean")
+            K = squareform(np.exp(-0.5 * d))
+            np.fill_diagonal(K, 1.0)
+            return K
+        return np.exp(-0.5 * cdist(X / ls, Y / ls, metric="sqeuclidean"))
     if Y is None:
-        d = pdist(X / ls, metric="sqeuclidean")
-        K = squareform(np.exp(-0.5 * d))
+        K = squareform(_shape(kind, pdist(X / ls, metric="euclidean")))
         np.fill_diagonal(K, 1.0)
         return K
-    d = cdist(X / ls, Y / ls, metric="sqeuclidean")
-    return np.exp(-0.5 * d)
+    return _shape(kind, cdist(X / ls, Y / ls, metric="euclidean"))
 
 
-def kernel_train(X, constant_value, length_scale, noise_level):
-    """kernel_(X): c*RBF + noise*I.  sklearn: kernels.py Product 931-989,
+def kernel_train(X, constant_value, length_scale, noise_level, kind="rbf"):
+    """kernel_(X): c*k + noise*I.  sklearn: kernels.py Product 931-989,
     Sum 833-889, ConstantKernel 1239-1310, WhiteKernel 1369-1440 (Y is None)."""
-    K = constant_value * rbf_gram(X, None, length_scale)
+    K = constant_value * rbf_gram(X, None, length_scale, kind)
     K[np.diag_indices_from(K)] += noise_level
     return K
 
 
-def kernel_cross(Xq, X, constant_value, length_scale):
+def kernel_cross(Xq, X, constant_value, length_scale, kind="rbf"):
     """kernel_(Xq, X): WhiteKernel contributes zeros for an explicit second
     argument (sklearn: kernels.py:1413-1414)."""
-    return constant_value * rbf_gram(Xq, X, length_scale)
+    return constant_value * rbf_gram(Xq, X, length_scale, kind)
 
 
 # --------------------------------------------------------------------------- sklearn GPR
-def gpr_fit(X, Y, constant_value, length_scale, noise_level, alpha=1e-10):
+def gpr_fit(X, Y, constant_value, length_scale, noise_level, alpha=1e-10, kind="rbf"):
     """L_, alpha_ as sklearn: _gpr.py:346-364 (K = kernel_(X); K[diag] += alpha;
     cholesky lower; cho_solve).  Raises numpy.linalg.LinAlgError on a non-PD K."""
-    K = kernel_train(X, constant_value, length_scale, noise_level)
+    K = kernel_train(X, constant_value, length_scale, noise_level, kind)
     K[np.diag_indices_from(K)] += alpha
     L = cholesky(K, lower=True, check_finite=False)
     a = cho_solve((L, True), Y, check_finite=False)
@@ -66,17 +88,17 @@ def gpr_fit(X, Y, constant_value, length_scale, noise_level, alpha=1e-10):
 
 
 def gpr_predict(Xq, X, L, a, constant_value, length_scale, noise_level,
-                return_std=False, return_cov=False):
+                return_std=False, return_cov=False, kind="rbf"):
     """sklearn: _gpr.py:441-494.  y_mean = K* alpha_; V = L \\ K*^T;
     var = diag(k**) - sum(V*V) clipped at 0, tiled over the targets; std = sqrt."""
-    Ks = kernel_cross(Xq, X, constant_value, length_scale)
+    Ks = kernel_cross(Xq, X, constant_value, length_scale, kind)
     mean = Ks @ a
     if not (return_std or return_cov):
         return mean
     V = solve_triangular(L, Ks.T, lower=True, check_finite=False)
     n_targets = a.shape[1] if a.ndim > 1 else 1
     if return_cov:
-        cov = kernel_train(Xq, constant_value, length_scale, noise_level) - V.T @ V
+        cov = kernel_train(Xq, constant_value, length_scale, noise_level, kind) - V.T @ V
         if n_targets > 1:
             cov = np.repeat(cov[..., None], n_targets, axis=-1)
         return mean, cov
@@ -88,7 +110,7 @@ def gpr_predict(Xq, X, L, a, constant_value, length_scale, noise_level,
     return mean, np.sqrt(var)
 
 
-def log_marginal_likelihood(theta, X, Y, n_ls, alpha=1e-10, eval_gradient=True):
+def log_marginal_likelihood(theta, X, Y, n_ls, alpha=1e-10, eval_gradient=True, kind="rbf"):
     """LML and its gradient w.r.t. log-hyper-parameters.  sklearn: _gpr.py:537-652.
 
     theta = log([constant_value, length_scale (n_ls of them), noise_level]) — the
@@ -99,7 +121,7 @@ def log_marginal_likelihood(theta, X, Y, n_ls, alpha=1e-10, eval_gradient=True):
     ls = np.exp(theta[1:1 + n_ls])
     noise = np.exp(theta[1 + n_ls])
     N = X.shape[0]
-    R = rbf_gram(X, None, ls if n_ls > 1 else ls[0])
+    R = rbf_gram(X, None, ls if n_ls > 1 else ls[0], kind)
     K = c * R
     K[np.diag_indices_from(K)] += noise + alpha
     try:
@@ -118,13 +140,26 @@ def log_marginal_likelihood(theta, X, Y, n_ls, alpha=1e-10, eval_gradient=True):
     grad = np.empty_like(theta)
     cR = c * R
     grad[0] = 0.5 * np.sum(inner * cR)          # dK/dlog c = c*R       (kernels.py:1290-1300)
-    if n_ls == 1:                               # isotropic: dK/dlog l = K * d2 (kernels.py:1568-1573)
-        d2 = squareform(pdist(X / ls[0], metric="sqeuclidean"))
-        grad[1] = 0.5 * np.sum(inner * cR * d2)
-    else:                                       # ARD: per-dimension (kernels.py:1574-1580)
+    # dK/dlog l_d = c * G * D_d with D_d = (x_d - x'_d)^2 / l_d^2 (summed over d when isotropic) and
+    # G = R (RBF, kernels.py:1568-1580), R / r (nu=1/2), 3 exp(-sqrt3 r) (3/2), 5/3 (sqrt5 r + 1) exp(-sqrt5 r)
+    # (5/2)  (Matern, kernels.py:1747-1778)
+    lsv = np.broadcast_to(ls, (X.shape[1],)) if n_ls == 1 else ls
+    Dd = (X[:, None, :] - X[None, :, :]) ** 2 / lsv ** 2          # (N, N, D)
+    r = np.sqrt(Dd.sum(-1))
+    if kind == "rbf":
+        G = R
+    elif kind == "matern12":
+        G = np.divide(R, r, out=np.zeros_like(R), where=r != 0)
+    elif kind == "matern32":
+        G = 3.0 * np.exp(-np.sqrt(3.0) * r)
+    else:
+        t = np.sqrt(5.0) * r
+        G = 5.0 / 3.0 * (t + 1.0) * np.exp(-t)
+    if n_ls == 1:
+        grad[1] = 0.5 * np.sum(inner * c * G * Dd.sum(-1))
+    else:
         for d in range(n_ls):
-            dd = (X[:, None, d] - X[None, :, d]) ** 2 / ls[d] ** 2
-            grad[1 + d] = 0.5 * np.sum(inner * cR * dd)
+            grad[1 + d] = 0.5 * np.sum(inner * c * G * Dd[:, :, d])
     grad[1 + n_ls] = 0.5 * noise * np.trace(inner)   # dK/dlog noise = noise*I (kernels.py:1403-1410)
     return lml, grad
 
@@ -134,7 +169,8 @@ class GaussianProcessOracle:
     """Restates ref: models/gaussian_process.py:16-126 for optimizer=None
     (fixed hyper-parameters).  Same attribute names, shapes and quirks."""
 
-    def __init__(self, constant_value, length_scale, noise_level, alpha=1e-10):
+    def __init__(self, constant_value, length_scale, noise_level, alpha=1e-10, kind="rbf"):
+        self.kind = kind
         self.constant_value = float(constant_value)
         self.length_scale = np.atleast_1d(np.asarray(length_scale, dtype=np.float64))
         self.noise_level = float(noise_level)
@@ -152,10 +188,10 @@ class GaussianProcessOracle:
         self.X = X[~mask]
         self.Y = Y[~mask]
         self.L_, self.alpha_ = gpr_fit(self.X, self.Y, self.constant_value, self._ls(),
-                                       self.noise_level, self.alpha)
+                                       self.noise_level, self.alpha, self.kind)
         self.noise_var_ = self.alpha + self.noise_level   # :40
         self.prior_var = self.constant_value               # :41
-        K_ = kernel_cross(self.X, self.X, self.constant_value, self._ls()) \
+        K_ = kernel_cross(self.X, self.X, self.constant_value, self._ls(), self.kind) \
             + self.noise_var_ * np.eye(len(self.X))        # :42
         self.K_inv = np.linalg.inv(K_)                     # :43
         return self
@@ -164,11 +200,11 @@ class GaussianProcessOracle:
         """ref: gaussian_process.py:46-55 (std - sqrt(noise_level) quirk at :49)."""
         args = (x, self.X, self.L_, self.alpha_, self.constant_value, self._ls(), self.noise_level)
         if return_std:
-            y, std = gpr_predict(*args, return_std=True)
+            y, std = gpr_predict(*args, return_std=True, kind=self.kind)
             return y, std - np.sqrt(self.noise_level)
         if return_cov:
-            return gpr_predict(*args, return_cov=True)
-        return gpr_predict(*args)
+            return gpr_predict(*args, return_cov=True, kind=self.kind)
+        return gpr_predict(*args, kind=self.kind)
 
     def samples(self, x, n_samples=10):
         """ref: gaussian_process.py:57-60 -> sklearn/_gpr.py:498-535 (sample_y, random_state=0):

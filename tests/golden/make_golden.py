@@ -152,6 +152,49 @@ def case_letterS(pt, resample):
     print("wrote letterS_2d", out["length_scale"], out["constant_value"], out["noise_var_"])
 
 
+def case_matern(pt, resample):
+    """The examples' dynamics GP (example/2D/surface_generalization.py:49-51: C(sqrt 0.1) * Matern(1, nu=2.5) +
+    White(0.01) on the resampled letter-S demo, optimizer on) and fixed-theta fits for nu = 0.5 / 1.5 / 2.5."""
+    from sklearn.gaussian_process.kernels import Matern, WhiteKernel, ConstantKernel as C
+    data = np.load(os.path.join(REF, "example/2D/data/example.npz"))
+    X = resample(data["demo"], num_points=400)
+    dX = np.zeros((len(X), 2)); dX[:-1] = X[1:] - X[:-1]
+    xg, yg = np.meshgrid(np.linspace(X[:, 0].min() - 10, X[:, 0].max() + 10, 15),
+                         np.linspace(X[:, 1].min() - 10, X[:, 1].max() + 10, 15))
+    grid = np.column_stack([xg.ravel(), yg.ravel()])
+    out = dict(X=X, Y=dX, grid=grid, alpha=np.float64(1e-10))
+    np.random.seed(0)
+    gp = pt.GaussianProcess(kernel=C(constant_value=np.sqrt(0.1)) * Matern(1 * np.ones(2), nu=2.5) + WhiteKernel(0.01))
+    gp.fit(X, dX)
+    m, s = gp.predict(grid, return_std=True)
+    out.update(opt_theta0=gp.gp.kernel.theta, opt_theta=gp.gp.kernel_.theta, opt_lml=np.float64(gp.gp.log_marginal_likelihood_value_),
+               opt_mean=m, opt_std=s)
+    rs = np.random.default_rng(5)
+    for nu, tag in ((0.5, "12"), (1.5, "32"), (2.5, "52")):
+        k = C(0.3) * Matern([1.5, 2.5], nu=nu) + WhiteKernel(0.01)
+        g2 = pt.GaussianProcess(kernel=k, optimizer=None)
+        g2.fit(X, dX)
+        m, s = g2.predict(grid, return_std=True)
+        _, cov = g2.predict(grid[:12], return_cov=True)
+        ths, vals, grads = [], [], []
+        base = g2.gp.kernel_.theta.copy()
+        for j in range(2):
+            th = base + j * rs.normal(0, 0.3, base.shape)
+            v, gr = g2.gp.log_marginal_likelihood(th, eval_gradient=True)
+            ths.append(th); vals.append(v); grads.append(gr)
+        out.update({f"m{tag}_mean": m, f"m{tag}_std": s, f"m{tag}_cov": cov, f"m{tag}_alpha_": g2.gp.alpha_,
+                    f"m{tag}_Ldiag": np.diag(g2.gp.L_).copy(), f"m{tag}_lml_theta": np.array(ths),
+                    f"m{tag}_lml_value": np.array(vals), f"m{tag}_lml_grad": np.array(grads)})
+        # isotropic variant gradient
+        ki = C(0.3) * Matern(2.0, nu=nu) + WhiteKernel(0.01)
+        g3 = pt.GaussianProcess(kernel=ki, optimizer=None)
+        g3.fit(X[::4], dX[::4])
+        v, gr = g3.gp.log_marginal_likelihood(g3.gp.kernel_.theta + 0.1, eval_gradient=True)
+        out.update({f"m{tag}_iso_theta": g3.gp.kernel_.theta + 0.1, f"m{tag}_iso_value": np.float64(v), f"m{tag}_iso_grad": gr})
+    np.savez_compressed(os.path.join(HERE, "matern_2d.npz"), **out)
+    print("wrote matern_2d", np.exp(out["opt_theta"]), out["opt_lml"])
+
+
 def case_surface3d(pt, optimize=True):
     """example/3D/surface_generalization_3D.py:50-61 flow (N=2500, default kernel).
     optimizer on takes ~5 min here; the fitted theta is stored and outputs come from
@@ -203,7 +246,7 @@ def case_n8192(pt):
 def main(argv):
     warnings.filterwarnings("ignore")
     pt, resample = import_reference()
-    cases = argv or ["n64", "n64iso", "n64nan", "n256", "n1024", "letterS"]
+    cases = argv or ["n64", "n64iso", "n64nan", "n256", "n1024", "letterS", "matern"]
     for c in cases:
         if c == "n64":
             case_synthetic(pt, 64, 48, "synthetic_3d_N64", with_cov=16)
@@ -217,6 +260,8 @@ def main(argv):
             case_synthetic(pt, 1024, 128, "synthetic_3d_N1024", with_L=False)
         elif c == "letterS":
             case_letterS(pt, resample)
+        elif c == "matern":
+            case_matern(pt, resample)
         elif c == "surface3d":
             case_surface3d(pt, optimize=True)
         elif c == "n8192":

@@ -218,7 +218,13 @@ def test_empty_query_and_errors():
     with pytest.raises(ValueError):
         GaussianProcess(kernel=C(1.0) * RBF(0.1) + WhiteKernel(1e-3), optimizer=None, n_targets=2, verbose=False).fit(X, Y)
     with pytest.raises(NotImplementedError):
-        GaussianProcess(kernel=C(1.0) * Matern(0.1) + WhiteKernel(1e-3), optimizer=None, verbose=False).fit(X, Y)
+        GaussianProcess(kernel=C(1.0) * Matern(0.1, nu=0.7) + WhiteKernel(1e-3), optimizer=None, verbose=False).fit(X, Y)
+    mt = GaussianProcess(kernel=C(1.0) * Matern(0.3) + WhiteKernel(1e-3), optimizer=None, verbose=False).fit(X, Y)
+    assert mt.predict(X[:5]).shape == (5, 3)
+    with pytest.raises(NotImplementedError):
+        mt.derivative(X[:5])                       # RBF-only formulas in the reference: refused for Matern
+    with pytest.raises(NotImplementedError):
+        mt.derivative_of_variance(X[:5])
     with pytest.raises(ValueError):
         GaussianProcess(kernel=RBF(0.1), optimizer=None, verbose=False).fit(X, Y)
 
@@ -471,3 +477,47 @@ def test_transport_orientation_runs_and_is_consistent():
     U, _, Vt = np.linalg.svd(Jphi)
     polar = U @ Vt
     assert np.max(np.abs(rotation_matrix_from_quaternion(out) - polar @ rotation_matrix_from_quaternion(ori))) < 5e-3
+
+
+@pytest.mark.parametrize("tag,nu,code", [("12", 0.5, 1), ("32", 1.5, 2), ("52", 2.5, 3)])
+def test_matern_kernels_vs_reference(tag, nu, code):
+    """C * Matern(nu) + White (the examples' dynamics GP): fit, mean, std, covariance and the LML gradient."""
+    from sklearn.gaussian_process.kernels import Matern, WhiteKernel, ConstantKernel as C
+    from gaussian_process_transportation_amd import GaussianProcess, _lib
+    g = load_golden("matern_2d")
+    gp = GaussianProcess(kernel=C(0.3) * Matern([1.5, 2.5], nu=nu) + WhiteKernel(0.01), optimizer=None, verbose=False)
+    gp.fit(g["X"], g["Y"])
+    assert_parity(gp.gp.alpha_, g[f"m{tag}_alpha_"], RTOL, "alpha_")
+    assert_parity(np.diag(gp.gp.L_), g[f"m{tag}_Ldiag"], RTOL, "diag L")
+    m, s = gp.predict(g["grid"], return_std=True)
+    assert_parity(m, g[f"m{tag}_mean"], RTOL, "mean")
+    assert_parity(s, g[f"m{tag}_std"], RTOL, "std")
+    _, cov = gp.predict(g["grid"][:12], return_cov=True)
+    assert_parity(cov, g[f"m{tag}_cov"], RTOL, "cov")
+    h = _lib.Handle(0)
+    for th, v, gr in zip(g[f"m{tag}_lml_theta"], g[f"m{tag}_lml_value"], g[f"m{tag}_lml_grad"]):
+        h.fit(g["X"], g["Y"], np.exp(th[1:3]), np.exp(th[0]), np.exp(th[3]), 1e-10, code)
+        lml, grad = h.lml_gradient(2)
+        assert lml == pytest.approx(float(v), rel=1e-9)
+        assert_parity(grad, gr, 1e-6, "d lml / d theta (ARD)")
+    th = g[f"m{tag}_iso_theta"]
+    h.fit(g["X"][::4], g["Y"][::4], np.exp(th[1:2]), np.exp(th[0]), np.exp(th[2]), 1e-10, code)
+    lml, grad = h.lml_gradient(1)
+    assert lml == pytest.approx(float(g[f"m{tag}_iso_value"]), rel=1e-9)
+    assert_parity(grad, g[f"m{tag}_iso_grad"], 1e-6, "d lml / d theta (isotropic)")
+    h.close()
+
+
+def test_matern_dynamics_gp_with_optimizer():
+    """example/2D/surface_generalization.py:49-51: the dynamics GP with its default optimizer."""
+    from sklearn.gaussian_process.kernels import Matern, WhiteKernel, ConstantKernel as C
+    from gaussian_process_transportation_amd import GaussianProcess
+    g = load_golden("matern_2d")
+    np.random.seed(0)
+    gp = GaussianProcess(kernel=C(constant_value=np.sqrt(0.1)) * Matern(1 * np.ones(2), nu=2.5) + WhiteKernel(0.01), verbose=False)
+    gp.fit(g["X"], g["Y"])
+    assert gp.gp.log_marginal_likelihood_value_ == pytest.approx(float(g["opt_lml"]), rel=1e-6)
+    assert_parity(np.asarray(gp.kernel.theta), g["opt_theta"], 1e-3, "fitted theta")
+    m, s = gp.predict(g["grid"], return_std=True)
+    assert_parity(m, g["opt_mean"], 1e-3, "mean")
+    assert_parity(s, g["opt_std"], 1e-3, "std")

@@ -114,3 +114,24 @@ def test_surface3d_transport():
     assert_parity(out["std"], g["std"], 1e-6, "std")
     assert_parity(out["vel"], g["vel"], 1e-6, "vel")
     assert_parity(out["var_vel"], g["var_vel"], 1e-5, "var_vel")
+
+
+@pytest.mark.parametrize("tag,kind", [("12", "matern12"), ("32", "matern32"), ("52", "matern52")])
+def test_matern_kernels(tag, kind):
+    """The examples' dynamics-GP kernel family (C * Matern(nu) + White) against the reference."""
+    g = load_golden("matern_2d")
+    gp = orc.GaussianProcessOracle(0.3, np.array([1.5, 2.5]), 0.01, kind=kind).fit(g["X"], g["Y"])
+    assert_parity(gp.alpha_, g[f"m{tag}_alpha_"], 1e-7, "alpha_")
+    assert_parity(np.diag(gp.L_), g[f"m{tag}_Ldiag"], TIGHT, "diag L")
+    m, s = gp.predict(g["grid"], return_std=True)
+    assert_parity(m, g[f"m{tag}_mean"], 1e-8, "mean")
+    assert_parity(s, g[f"m{tag}_std"], 1e-7, "std")
+    _, cov = gp.predict(g["grid"][:12], return_cov=True)
+    assert_parity(cov, g[f"m{tag}_cov"], 1e-7, "cov")
+    for th, v, gr in zip(g[f"m{tag}_lml_theta"], g[f"m{tag}_lml_value"], g[f"m{tag}_lml_grad"]):
+        val, grad = orc.log_marginal_likelihood(th, g["X"], g["Y"], 2, kind=kind)
+        assert val == pytest.approx(float(v), rel=1e-10)
+        assert_parity(grad, gr, 1e-7, "lml grad (ARD)")
+    val, grad = orc.log_marginal_likelihood(g[f"m{tag}_iso_theta"], g["X"][::4], g["Y"][::4], 1, kind=kind)
+    assert val == pytest.approx(float(g[f"m{tag}_iso_value"]), rel=1e-10)
+    assert_parity(grad, g[f"m{tag}_iso_grad"], 1e-7, "lml grad (isotropic)")
