@@ -29,6 +29,7 @@ SIGNATURES = {
     "gpt_synchronize": (C.c_int, [_vp]),
     "gpt_fit": (C.c_int, [_vp, _dp, _dp, _i64, C.c_int, C.c_int, _dp, C.c_int, C.c_double, C.c_double, C.c_double]),
     "gpt_fit_kernel": (C.c_int, [_vp, _dp, _dp, _i64, C.c_int, C.c_int, _dp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int]),
+    "gpt_fit_noise_matrix": (C.c_int, [_vp, _dp, _dp, _i64, C.c_int, C.c_int, _dp, C.c_int, C.c_double, _dp, C.c_double, C.c_int]),
     "gpt_predict": (C.c_int, [_vp, _dp, _i64, _dp, _dp]),
     "gpt_derivative": (C.c_int, [_vp, _dp, _i64, _dp, _dp]),
     "gpt_dvariance": (C.c_int, [_vp, _dp, _i64, _dp]),
@@ -161,6 +162,19 @@ class Handle:
             raise ValueError("X and Y have different numbers of rows")
         check(self.lib.gpt_fit_kernel(self._h, dptr(X), dptr(Y), N, D, Y.shape[1], dptr(ls), ls.size,
                                       float(constant_value), float(noise_level), float(alpha), int(kernel_type)), "gpt_fit")
+
+    def fit_noise_matrix(self, X, Y, length_scale, constant_value, Sigma, alpha=0.0, kernel_type=0):
+        """K = c k(X,X) + Sigma (full SPD (N,N)) + alpha I — the SVGP exact-conversion model."""
+        X = as_f64(X, 2)
+        Y = as_f64(Y, 2)
+        Sigma = as_f64(Sigma, 2)
+        ls = as_f64(np.atleast_1d(length_scale), 1)
+        N, D = X.shape
+        if Y.shape[0] != N or Sigma.shape != (N, N):
+            raise ValueError("X, Y and Sigma disagree on the number of points")
+        check(self.lib.gpt_fit_noise_matrix(self._h, dptr(X), dptr(Y), N, D, Y.shape[1], dptr(ls), ls.size,
+                                            float(constant_value), dptr(Sigma), float(alpha), int(kernel_type)),
+              "gpt_fit_noise_matrix")
 
     def info(self):
         N, NP, D, O = _i64(), _i64(), C.c_int(), C.c_int()

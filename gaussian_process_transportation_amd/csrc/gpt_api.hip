@@ -230,9 +230,26 @@ int gpt_fit(gpt_handle* h, const double* X, const double* Y, int64_t N, int D, i
     return gpt_fit_kernel(h, X, Y, N, D, O, length_scale, n_ls, constant_value, noise_level, alpha_jitter, GPT_KERNEL_RBF);
 }
 
+static int fit_impl(gpt_handle* h, const double* X, const double* Y, int64_t N, int D, int O,
+                    const double* length_scale, int n_ls, double constant_value, double noise_level,
+                    double alpha_jitter, int kernel_type, const double* Sigma);
+
 int gpt_fit_kernel(gpt_handle* h, const double* X, const double* Y, int64_t N, int D, int O,
                    const double* length_scale, int n_ls, double constant_value, double noise_level,
                    double alpha_jitter, int kernel_type) {
+    return fit_impl(h, X, Y, N, D, O, length_scale, n_ls, constant_value, noise_level, alpha_jitter, kernel_type, nullptr);
+}
+
+int gpt_fit_noise_matrix(gpt_handle* h, const double* X, const double* Y, int64_t N, int D, int O,
+                         const double* length_scale, int n_ls, double constant_value, const double* Sigma,
+                         double alpha_jitter, int kernel_type) {
+    if (!Sigma) return fail(GPT_E_ARG, "gpt_fit_noise_matrix: Sigma is NULL");
+    return fit_impl(h, X, Y, N, D, O, length_scale, n_ls, constant_value, 0.0, alpha_jitter, kernel_type, Sigma);
+}
+
+static int fit_impl(gpt_handle* h, const double* X, const double* Y, int64_t N, int D, int O,
+                    const double* length_scale, int n_ls, double constant_value, double noise_level,
+                    double alpha_jitter, int kernel_type, const double* Sigma) {
     if (!h || !X || !Y || !length_scale) return fail(GPT_E_ARG, "gpt_fit: NULL argument");
     if (kernel_type < GPT_KERNEL_RBF || kernel_type > GPT_KERNEL_MATERN52) return fail(GPT_E_ARG, "gpt_fit: unknown kernel_type");
     if (N < 1 || N > (1 << 20)) return fail(GPT_E_ARG, "gpt_fit: N out of range");
@@ -274,6 +291,11 @@ int gpt_fit_kernel(gpt_handle* h, const double* X, const double* Y, int64_t N, i
     HIPCHK(hipMemsetAsync(h->dinfo, 0, sizeof(int), s));
     HIPCHK(hipMemsetAsync(h->dW, 0, (size_t)NP * NP * sizeof(double), s));
     launch_gram(s, h->dXs(), (int)N, NP, kernel_type, constant_value, noise_level + alpha_jitter, h->dK);
+    if (Sigma) {      // K += Sigma: staged through dW (not in use until the factorisation starts)
+        HIPCHK(hipMemcpyAsync(h->dW, Sigma, (size_t)N * N * sizeof(double), hipMemcpyHostToDevice, s));
+        launch_add_lower(s, h->dK, h->dW, (int)N, NP);
+        HIPCHK(hipMemsetAsync(h->dW, 0, (size_t)NP * NP * sizeof(double), s));
+    }
     HIPCHK(hipEventRecord(h->ev[1], s));
     launch_potrf(s, h->dK, h->dW, NP, h->dinfo);
     HIPCHK(hipEventRecord(h->ev[2], s));

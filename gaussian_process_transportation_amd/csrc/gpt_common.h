@@ -39,6 +39,7 @@ struct KernelParams {
 // ---- launchers (defined in the .hip files) --------------------------------------------
 // fit
 void launch_gram(hipStream_t s, const double* Xs, int N, int NP, int ktype, double c, double diag_add, double* K);
+void launch_add_lower(hipStream_t s, double* K, const double* S, int N, int NP);
 void launch_potrf(hipStream_t s, double* K, double* W, int NP, int* info);
 void launch_trinv(hipStream_t s, const double* L, double* W, int NP, double* scratch /* >= NP*NP/4 doubles */);
 void launch_alpha(hipStream_t s, const double* W, const double* Y4, int N, int NP, double* tmp4, double* A4);

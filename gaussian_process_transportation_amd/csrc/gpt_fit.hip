@@ -56,6 +56,20 @@ void launch_gram(hipStream_t s, const double* Xs, int N, int NP, int ktype, doub
     hipLaunchKernelGGL(k_gram, grid, dim3(256), 0, s, Xs, N, NP, ktype, c, diag_add, K);
 }
 
+// K[i][j] += S[i][j] on the lower triangle of the first N rows (S row-major N x N, symmetric): the general
+// SPD "noise" matrix of the SVGP exact-conversion model (K_uu + Sigma_pseudo).
+__global__ __launch_bounds__(256) void k_add_lower(double* __restrict__ K, const double* __restrict__ S, int N, int NP) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)N * N) return;
+    const int i = (int)(e / N), j = (int)(e % N);
+    if (j <= i) K[(size_t)i * NP + j] += S[e];
+}
+
+void launch_add_lower(hipStream_t s, double* K, const double* S, int N, int NP) {
+    const int64_t tot = (int64_t)N * N;
+    hipLaunchKernelGGL(k_add_lower, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, K, S, N, NP);
+}
+
 // =====================================================================================
 // Diagonal block: unblocked Cholesky of one NB x NB block in LDS + its triangular inverse.
 // One workgroup.  Writes L_kk into K (zeros above the diagonal) and L_kk^-1 into W.

@@ -73,6 +73,16 @@ int gpt_fit_kernel(gpt_handle* h, const double* X, const double* Y, int64_t N, i
                    const double* length_scale, int n_ls, double constant_value, double noise_level,
                    double alpha_jitter, int kernel_type);
 
+/* Exact-GP algebra on SVGP pseudo-points — the fit behind the reference's `convert_to_exact_gp`
+ * (policy_transportation/models/torch/stocastic_variational_gaussian_process_derivatives.py:72-78):
+ * K = c*k(X,X) + Sigma + alpha_jitter*I with a full SPD matrix Sigma (N,N) (the per-task pseudo-point covariance)
+ * in place of the scalar noise; alpha = K^-1 Y.  One handle per task (O = 1, c = that task's outputscale).
+ * Afterwards gpt_predict_all gives mean, var = c - k*^T K^-1 k* (k** carries no noise: :120-123), the Jacobian
+ * and its variance c/l_d^2 - dk_d^T K^-1 dk_d (:132-153).  Host memory. */
+int gpt_fit_noise_matrix(gpt_handle* h, const double* X, const double* Y, int64_t N, int D, int O,
+                         const double* length_scale, int n_ls, double constant_value, const double* Sigma,
+                         double alpha_jitter, int kernel_type);
+
 /* predict — replaces GaussianProcess.predict (gaussian_process.py:46-55 -> sklearn/_gpr.py:441-494).
  * mean (M,O); var (M,) = max(c + noise_level - |L^-1 k*|^2, 0) (the caller applies sqrt, the
  * tiling over O and the reference's `- sqrt(noise_level)` quirk).  var may be NULL. Host memory. */

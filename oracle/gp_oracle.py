@@ -357,6 +357,32 @@ def resample_oracle(surface, num_points=20):
     return np.array(out)
 
 
+def svgp_exact_oracle(x, Z, Sigma, y, outputscale, lengthscale):
+    """ref: models/torch/stocastic_variational_gaussian_process_derivatives.py:72-78 (K_inv = inv(K_uu + Sigma),
+    alpha = K_inv y), :113-129 (mean = k* alpha, std = sqrt(diag(k** - k* K_inv k*^T)), k** = outputscale),
+    :132-153 (J = dk*/dx alpha, var' = outputscale/l_d^2 - diag(dk* K_inv dk*^T)); gpytorch ScaleKernel(RBF ARD):
+    outputscale_t exp(-0.5 |(x-z)/l|^2).  K_inv[t] per task (see svgp_exact.py on the reference's :142).
+    PARITY UNPINNED (gpytorch absent, no fixture in the reference).  Returns mean (M,T), std (M,T), J (M,T,D),
+    J_std (M,T,D)."""
+    ls = np.broadcast_to(np.atleast_1d(np.asarray(lengthscale, np.float64)), (Z.shape[1],))
+    T = Sigma.shape[0]
+    M, D = x.shape
+    R = np.exp(-0.5 * cdist(x / ls, Z / ls, metric="sqeuclidean"))            # (M,Z)
+    Ruu = np.exp(-0.5 * cdist(Z / ls, Z / ls, metric="sqeuclidean"))
+    mean = np.empty((M, T)); std = np.empty((M, T)); J = np.empty((M, T, D)); Js = np.empty((M, T, D))
+    for t in range(T):
+        Kinv = np.linalg.inv(outputscale[t] * Ruu + Sigma[t])
+        a = Kinv @ np.reshape(y[t], (-1,))
+        ks = outputscale[t] * R
+        mean[:, t] = ks @ a
+        std[:, t] = np.sqrt(outputscale[t] - np.einsum("mz,zw,mw->m", ks, Kinv, ks))
+        for d in range(D):
+            dk = (Z[None, :, d] - x[:, None, d]) / ls[d] ** 2 * ks
+            J[:, t, d] = dk @ a
+            Js[:, t, d] = np.sqrt(outputscale[t] / ls[d] ** 2 - np.einsum("mz,zw,mw->m", dk, Kinv, dk))
+    return mean, std, J, Js
+
+
 def synthetic_problem(N, M, D=3, seed=0, qseed=1):
     """SURVEY §8d synthetic inputs (identical for CPU and GPU)."""
     rng = np.random.default_rng(seed)

@@ -521,3 +521,47 @@ def test_matern_dynamics_gp_with_optimizer():
     m, s = gp.predict(g["grid"], return_std=True)
     assert_parity(m, g["opt_mean"], 1e-3, "mean")
     assert_parity(s, g["opt_std"], 1e-3, "std")
+
+
+def test_letter_s_example_end_to_end():
+    """Config 1: the reference's 2-D demo flow, headless (examples/letter_s_2d.py), against the golden
+    transported trajectory / velocities."""
+    import importlib.util
+    import os
+    from tests.conftest import ROOT
+    spec = importlib.util.spec_from_file_location("letter_s_2d", os.path.join(ROOT, "examples", "letter_s_2d.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = mod.main(verbose=False)
+    g = load_golden("letterS_2d")
+    assert_parity(out["X1"], g["traj"], 1e-3, "transported demo")
+    assert_parity(out["deltaX1"], g["vel"], 1e-3, "transported velocities")
+    assert out["field"].shape == (10000, 2) and np.all(np.isfinite(out["field1"]))
+
+
+@pytest.mark.parametrize("Z,M", [(200, 700), (1024, 3000)])
+def test_svgp_exact_conversion_predictor(Z, M):
+    """Config 5 algebra (synthetic SPD Sigma_pseudo = A A^T / Z + 1e-3 I, y ~ N(0,1), outputscale 1,
+    l = 0.2, T = D = 3) against the CPU restatement.  Parity unpinned (no gpytorch, no reference fixture)."""
+    from gaussian_process_transportation_amd.svgp_exact import SVGPExactPredictor
+    from oracle import gp_oracle as orc
+    rng = np.random.default_rng(0)
+    T = D = 3
+    Zp = rng.uniform(0, 1, (Z, D))
+    A = rng.standard_normal((T, Z, Z))
+    Sigma = A @ np.transpose(A, (0, 2, 1)) / Z + 1e-3 * np.eye(Z)
+    y = rng.standard_normal((T, Z, 1))
+    osc = np.array([1.0, 0.7, 1.3])
+    ls = np.array([0.2, 0.25, 0.15])
+    x = rng.uniform(0, 1, (M, D))
+    sv = SVGPExactPredictor(Zp, Sigma, y, osc, ls)
+    mean, std = sv.posterior_f(x, return_std=True)
+    J, Jstd = sv.posterior_f_prime(x, return_std=True)
+    rm, rs, rJ, rJs = orc.svgp_exact_oracle(x, Zp, Sigma, y, osc, ls)
+    assert mean.shape == (M, T) and J.shape == (M, T, D)
+    assert_parity(mean, rm, RTOL, "mean")
+    assert_parity(std, rs, RTOL, "std")
+    assert_parity(J, rJ, RTOL, "J")
+    assert_parity(Jstd, rJs, RTOL, "J std")
+    assert_parity(sv.predict(x), rm, RTOL, "predict alias")
+    sv.close()
