@@ -78,57 +78,88 @@ void launch_add_lower(hipStream_t s, double* K, const double* S, int N, int NP) 
 // =====================================================================================
 constexpr int DS = NB + 1;   // LDS row stride (doubles)
 
+// Thread t = 4*row + q holds the row's elements of columns c = q + 4m (m = 0..15) in registers for the whole
+// factorisation; at step j the owners of column j publish it through a double-buffered 64-entry LDS vector
+// (one barrier per step), everybody updates its registers: a[c] -= a[row][j] a[c][j] / a[j][j].
+// The inverse is a forward substitution with 4 lanes per column sharing each dot product.
 __global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ K, double* __restrict__ W, int NP, int kb,
                                                     int* __restrict__ info) {
+    __shared__ double colb[2][NB];
+    __shared__ double dsq[NB], dinv[NB];
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* A = smem;                 // [NB][DS]
-    double* X = smem + NB * DS;       // [NB][DS]
-    double* dsq = X + NB * DS;        // [NB]
-    double* dinv = dsq + NB;          // [NB]
+    double* Ls = smem;                      // L, row-major [NB][DS]
+    double* Xs = smem + NB * DS;            // L^-1, row-major [NB][DS]
     const int t = threadIdx.x;
+    const int row = t >> 2, q = t & 3;
     const int k0 = kb * NB;
-    for (int e = t; e < NB * NB; e += 256) {
-        const int r = e / NB, c = e % NB;
-        A[r * DS + c] = (c <= r) ? K[(size_t)(k0 + r) * NP + k0 + c] : 0.0;
-        X[r * DS + c] = 0.0;
+    double a[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        const int c = q + 4 * m;
+        a[m] = (c <= row) ? K[(size_t)(k0 + row) * NP + k0 + c] : 0.0;
     }
-    const int ui = t >> 2, uc = t & 3;
+    bool bad_seen = false;
+#pragma unroll
     for (int j = 0; j < NB; ++j) {
+        if (q == (j & 3)) colb[j & 1][row] = a[j >> 2];
         __syncthreads();
-        double d = A[j * DS + j];
-        if (!(d > 0.0)) {            // also catches NaN
-            if (t == 0) atomicCAS(info, 0, k0 + j + 1);
+        double d = colb[j & 1][j];
+        if (!(d > 0.0)) {            // also catches NaN; uniform over the workgroup
+            if (t == 0 && !bad_seen) atomicCAS(info, 0, k0 + j + 1);
+            bad_seen = true;
             d = 1.0;
         }
-        if (t == 0) { const double s = sqrt(d); dsq[j] = s; dinv[j] = 1.0 / s; }
-        if (ui > j) {
-            const double f = A[ui * DS + j] / d;
-            for (int c = j + 1 + ((uc - (j + 1)) & 3); c <= ui; c += 4) A[ui * DS + c] -= f * A[c * DS + j];
+        if (t == 0) { const double sd = sqrt(d); dsq[j] = sd; dinv[j] = 1.0 / sd; }
+        if (row > j) {
+            // 1/d by v_rcp_f64 + two Newton steps (<= 2 ulp) instead of the ~14-instruction IEEE division chain
+            double rinv = __builtin_amdgcn_rcp(d);
+            rinv = fma(fma(-d, rinv, 1.0), rinv, rinv);
+            rinv = fma(fma(-d, rinv, 1.0), rinv, rinv);
+            const double f = colb[j & 1][row] * rinv;
+#pragma unroll
+            for (int m = (j >> 2); m < 16; ++m) {
+                const int c = q + 4 * m;
+                if (c > j && c <= row) a[m] -= f * colb[j & 1][c];
+            }
         }
     }
     __syncthreads();
-    for (int e = t; e < NB * NB; e += 256) {
-        const int r = e / NB, c = e % NB;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        const int c = q + 4 * m;
         double v = 0.0;
-        if (c < r) v = A[r * DS + c] * dinv[c];
-        else if (c == r) v = dsq[r];
-        A[r * DS + c] = v;
+        if (c < row) v = a[m] * dinv[c];
+        else if (c == row) v = dsq[row];
+        Ls[row * DS + c] = v;
+        K[(size_t)(k0 + row) * NP + k0 + c] = v;
     }
     __syncthreads();
-    // inverse: thread c owns column c of X = L^-1 (forward substitution, uniform loop bounds)
-    if (t < NB) {
-        const int c = t;
+    // inverse: lanes 4c..4c+3 own column c of X = L^-1; lane p keeps x[k], k = p (mod 4), in registers and sums
+    // those terms of each row's dot product; the row result is shared by two lane exchanges
+    {
+        const int c = t >> 2, p = t & 3;
+        double xr[16];
+#pragma unroll
+        for (int m = 0; m < 16; ++m) xr[m] = 0.0;
+#pragma unroll
         for (int i = 0; i < NB; ++i) {
-            double s = (i == c) ? 1.0 : 0.0;
-            for (int k = 0; k < i; ++k) s -= A[i * DS + k] * X[k * DS + c];
-            X[i * DS + c] = (i >= c) ? s * dinv[i] : 0.0;
+            double sp = 0.0;
+#pragma unroll
+            for (int m = 0; m < (i + 3) / 4; ++m) {
+                const int k = p + 4 * m;
+                if (k < i) sp = fma(Ls[i * DS + k], xr[m], sp);       // x[k] = 0 for k < c
+            }
+            sp += __shfl_xor(sp, 1);
+            sp += __shfl_xor(sp, 2);
+            const double x = (i >= c) ? (((i == c) ? 1.0 : 0.0) - sp) * dinv[i] : 0.0;
+            if (p == (i & 3)) xr[i >> 2] = x;
+            if (p == 0) Xs[i * DS + c] = x;
         }
     }
     __syncthreads();
     for (int e = t; e < NB * NB; e += 256) {
         const int r = e / NB, c = e % NB;
-        K[(size_t)(k0 + r) * NP + k0 + c] = A[r * DS + c];
-        W[(size_t)(k0 + r) * NP + k0 + c] = X[r * DS + c];
+        W[(size_t)(k0 + r) * NP + k0 + c] = Xs[r * DS + c];
     }
 }
 
@@ -279,14 +310,40 @@ static void launch_gemm(hipStream_t s, const GemmArgs& g) {
 //   diag block (LDS, + inverse)  ->  panel  L21 = A21 * inv(L11)^T  (MFMA GEMM, in place)
 //   ->  trailing  A22 -= L21 L21^T  (MFMA GEMM on the block lower triangle).
 // =====================================================================================
+// Look-ahead: the trailing update of step k is split into the next block column (needed by the next diagonal
+// block and panel; stays on the main stream) and the rest (side stream), so that the serial diagonal-block and
+// panel kernels of step k+1 run underneath the bulk of step k's update.  Both parts of consecutive steps touch
+// the same block column, so the column part of step k+1 waits for the bulk of step k.
+struct PotrfStreams {
+    hipStream_t side = nullptr;
+    hipEvent_t panel_done[2] = {nullptr, nullptr};   // ping-pong: panel(k) finished on the main stream
+    hipEvent_t bulk_done[2] = {nullptr, nullptr};    // bulk(k) finished on the side stream
+    bool ok = false;
+};
+
+static PotrfStreams& potrf_streams() {
+    static PotrfStreams ps;
+    if (!ps.side) {
+        ps.ok = hipStreamCreateWithFlags(&ps.side, hipStreamNonBlocking) == hipSuccess;
+        for (int i = 0; i < 2 && ps.ok; ++i)
+            ps.ok = hipEventCreateWithFlags(&ps.panel_done[i], hipEventDisableTiming) == hipSuccess &&
+                    hipEventCreateWithFlags(&ps.bulk_done[i], hipEventDisableTiming) == hipSuccess;
+    }
+    return ps;
+}
+
 void launch_potrf(hipStream_t s, double* K, double* W, int NP, int* info) {
     const int nb = NP / NB;
-    constexpr size_t diag_lds = (size_t)(2 * NB * DS + 2 * NB) * sizeof(double);
+    constexpr size_t diag_lds = (size_t)(2 * NB * DS) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_diag), hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_lds);
         attr_set = true;
     }
+    PotrfStreams& ps = potrf_streams();
+    const bool lookahead = ps.ok && nb > 4;
+    bool bulk_pending = false;
+    int pending_slot = 0;
     for (int kb = 0; kb < nb; ++kb) {
         hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), diag_lds, s, K, W, NP, kb, info);
         const int r0 = (kb + 1) * NB;
@@ -299,14 +356,36 @@ void launch_potrf(hipStream_t s, double* K, double* W, int NP, int* info) {
         p.M = p.M_last = rem; p.N = NB; p.K = p.K_last = NB; p.nbatch = 1;
         p.alpha = 1.0; p.beta = 0.0;
         launch_gemm<true>(s, p);
+        // trailing update A22 -= L21 L21^T: block column r0 .. r0+NB-1 first
+        if (bulk_pending) hipStreamWaitEvent(s, ps.bulk_done[pending_slot], 0);   // bulk(k-1) also wrote this column
+        bulk_pending = false;
+        GemmArgs c{};
+        c.A = K + (size_t)r0 * NP + kb * NB; c.lda = NP;
+        c.B = c.A; c.ldb = NP;
+        c.C = K + (size_t)r0 * NP + r0; c.ldc = NP;
+        c.M = c.M_last = rem; c.N = NB; c.K = c.K_last = NB; c.nbatch = 1;
+        c.alpha = -1.0; c.beta = 1.0; c.lower_only = 1;
+        launch_gemm<true>(s, c);
+        const int rem2 = rem - NB;
+        if (rem2 <= 0) continue;
         GemmArgs u{};
-        u.A = K + (size_t)r0 * NP + kb * NB; u.lda = NP;
+        u.A = K + (size_t)(r0 + NB) * NP + kb * NB; u.lda = NP;
         u.B = u.A; u.ldb = NP;
-        u.C = K + (size_t)r0 * NP + r0; u.ldc = NP;
-        u.M = u.M_last = rem; u.N = rem; u.K = u.K_last = NB; u.nbatch = 1;
+        u.C = K + (size_t)(r0 + NB) * NP + (r0 + NB); u.ldc = NP;
+        u.M = u.M_last = rem2; u.N = rem2; u.K = u.K_last = NB; u.nbatch = 1;
         u.alpha = -1.0; u.beta = 1.0; u.lower_only = 1;
-        launch_gemm<true>(s, u);
+        if (lookahead) {
+            const int slot = kb & 1;
+            hipEventRecord(ps.panel_done[slot], s);                 // panel(k) (and column part) issued before this point
+            hipStreamWaitEvent(ps.side, ps.panel_done[slot], 0);
+            launch_gemm<true>(ps.side, u);
+            hipEventRecord(ps.bulk_done[slot], ps.side);
+            bulk_pending = true; pending_slot = slot;
+        } else {
+            launch_gemm<true>(s, u);
+        }
     }
+    if (bulk_pending) hipStreamWaitEvent(s, ps.bulk_done[pending_slot], 0);
 }
 
 // =====================================================================================
