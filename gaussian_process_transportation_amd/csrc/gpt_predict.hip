@@ -163,6 +163,12 @@ void launch_mean_jac(hipStream_t s, const KernelParams& p, const double* Xs, con
 // hit rate 97 % -> 56 %, 3.4 TB/s from beyond L2, clock 2.18 GHz), deeper A prefetch (0 %).
 // NCOMP = 1: one column per query (k*).  NCOMP = 4: four columns per query (k*, dk_0, dk_1, dk_2).
 // ------------------------------------------------------------------------------------------
+// Timing-only ablation builds (results are wrong unless 0): -DGPT_ABL=1 no per-chunk barrier, 2 no A-operand
+// loads, 3 diagonal tile skipped, 4 no B fill (LDS image left as is), 5 no MFMAs.  tools/gpu_ablate.sh,
+// profiles/r01_final_ablation.txt.
+#ifndef GPT_ABL
+#define GPT_ABL 0
+#endif
 constexpr int VAR_COLS = 64;        // columns per column block
 constexpr int VAR_SUB = 8;          // k4-steps per sub-chunk (= waves per workgroup: wave w fills step w of each)
 constexpr int VAR_SUBS = 4;         // sub-chunks per LDS chunk
@@ -340,25 +346,26 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlan pl, cons
                     const int k0 = ch * VAR_CH + sub * VAR_SUB;                 // first k-step of this sub-chunk
                     const int kn = (ch + 1) * VAR_CH + sub * VAR_SUB + w;       // the k-step this wave fills meanwhile
                     if (more) fetch(kn);
-                    const bool active = k0 < my_limit;          // my_limit is a multiple of 16: all or nothing
+                    const bool active = (k0 < my_limit) && !(GPT_ABL == 3 && k0 >= ib * WT_K4);   // my_limit is a multiple of 16: all or nothing
                     auto step = [&](const int s) {
                         const int k4 = k0 + s;
                         const d2 a01 = a_nxt[0], a23 = a_nxt[1];
                         const d4 b = b_nxt;
                         const size_t Sn = S_ib + ((k4 + 1 < my_limit) ? (k4 + 1) : k4);
-                        a_nxt[0] = wbase[Sn * STEP_D2]; a_nxt[1] = wbase[Sn * STEP_D2 + 64];
+                        if (GPT_ABL != 2) { a_nxt[0] = wbase[Sn * STEP_D2]; a_nxt[1] = wbase[Sn * STEP_D2 + 64]; }
                         const int sn = sub * VAR_SUB + s + 1;
                         if (sn < VAR_CH) b_nxt = *reinterpret_cast<const d4*>(Bs(cur, sn));
+                        if (GPT_ABL == 5) { asm volatile("" :: "v"(a01), "v"(a23), "v"(b)); return; }
                         GPT_MFMA16(acc, a01, a23, b);
                     };
                     if (active) { step(0); step(1); }
-                    if (more && w < 4) produce(cur ^ 1, kn);
+                    if (more && w < 4 && GPT_ABL != 4) produce(cur ^ 1, kn);
                     if (active) { step(2); step(3); step(4); step(5); }
-                    if (more && w >= 4) produce(cur ^ 1, kn);
+                    if (more && w >= 4 && GPT_ABL != 4) produce(cur ^ 1, kn);
                     if (active) { step(6); step(7); }
                     else if (sub + 1 < VAR_SUBS) b_nxt = *reinterpret_cast<const d4*>(Bs(cur, (sub + 1) * VAR_SUB));
                 }
-                __syncthreads();
+                if (GPT_ABL != 1) __syncthreads();
             }
             // i-block finished: fold this wave's 64 rows of V into the per-column sums
 #pragma unroll
