@@ -565,3 +565,18 @@ def test_svgp_exact_conversion_predictor(Z, M):
     assert_parity(Jstd, rJs, RTOL, "J std")
     assert_parity(sv.predict(x), rm, RTOL, "predict alias")
     sv.close()
+
+
+def test_surface_3d_example_end_to_end():
+    """The reference's 3-D demo flow, headless (examples/surface_3d.py), optimizer on, against the golden outputs."""
+    import importlib.util
+    import os
+    from tests.conftest import ROOT
+    spec = importlib.util.spec_from_file_location("surface_3d", os.path.join(ROOT, "examples", "surface_3d.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = mod.main(verbose=False)
+    g = load_golden("surface_3d")
+    assert_parity(out["theta"], g["theta_fit"], 1e-3, "fitted theta")
+    assert_parity(out["X1"], g["traj"], 1e-4, "transported demo")
+    assert_parity(out["deltaX1"], g["vel"], 1e-3, "transported velocities")
