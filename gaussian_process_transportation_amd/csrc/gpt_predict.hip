@@ -154,7 +154,10 @@ void launch_mean_jac(hipStream_t s, const KernelParams& p, const double* Xs, con
 //     block pays N exps per column, not N*(N/512+1)/2;
 //   * the A operand streams from the fragment-ordered image Wf with two 16-byte loads per lane and
 //     k-step, one step ahead; in the diagonal tile a wave skips the k-steps where its row group is
-//     entirely above the diagonal, row groups paired (0,7)(1,6)(2,5)(3,4) on the SIMDs;
+//     entirely above the diagonal (wave g has 16 (g + 1) of 128), row groups paired (0,7)(1,6)(2,5)(3,4) on
+//     the SIMDs.  In the reload sweeps the diagonal tile runs OUTSIDE the lock-step LDS pipeline (every wave
+//     on its own, B straight from the scratch image), so the pairing balances it: 0.56 of a full tile
+//     instead of 0.75 (+2.7 %);
 //   * work split: rounds of whole blocks (all workgroups in step => W tiles are shared through L2), then
 //     a stream-K split of the leftover blocks; partial column sums go to unique slab slots and
 //     k_var_finalize adds them in fixed order (deterministic, no atomics).
@@ -174,7 +177,7 @@ constexpr int VAR_SUB = 8;          // k4-steps per sub-chunk (= waves per workg
 constexpr int VAR_SUBS = 4;         // sub-chunks per LDS chunk
 constexpr int VAR_CH = VAR_SUB * VAR_SUBS;   // k4-steps per LDS chunk, one barrier each (32)
 constexpr size_t VAR_LDS_BYTES = (size_t)2 * VAR_CH * 64 * 4 * sizeof(double);   // 128 KiB
-constexpr int VAR_DIAG_COST = 96;   // k4-steps a diagonal tile costs (chunks of 32 in lock-step: 64+64+32+32 of 2 x 128, halved)
+constexpr int VAR_DIAG_COST = 72;   // k4-steps a diagonal tile costs a SIMD: waves g and 7-g, 16 (g+1) + 16 (8-g) of 2 x 128, halved
 constexpr int VAR_SLOT = 2 * VAR_COLS;   // doubles per slab slot: ssq[64], crs[64]
 
 // Work split.  Rounds 0..R-1: workgroup p takes the whole column block r*P + p — all workgroups then walk
@@ -322,10 +325,12 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlan pl, cons
             };
 
             const size_t S_ib = (size_t)64 * ib * (ib + 1);   // stream index of the first k4-step of this sweep
+            if (GEN || ib > 0) {
 #pragma unroll
-            for (int j = 0; j < VAR_SUBS; ++j) {              // chunk 0: wave w fills steps w, w+8, w+16, w+24
-                fetch(j * VAR_SUB + w);
-                produce(0, j * VAR_SUB + w);
+                for (int j = 0; j < VAR_SUBS; ++j) {          // chunk 0: wave w fills steps w, w+8, w+16, w+24
+                    fetch(j * VAR_SUB + w);
+                    produce(0, j * VAR_SUB + w);
+                }
             }
             d2 a_nxt[2];
             a_nxt[0] = wbase[S_ib * STEP_D2]; a_nxt[1] = wbase[S_ib * STEP_D2 + 64];   // step 0 is active for every group
@@ -337,7 +342,10 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlan pl, cons
                 for (int t = 0; t < 4; ++t) acc[r][t] = d4{0, 0, 0, 0};
             const int nk4 = (ib + 1) * WT_K4;
             const int my_limit = ib * WT_K4 + 16 * (g + 1);     // first k4-step of the sweep with nothing left for this group
-            const int nchunks = nk4 / VAR_CH;
+            // Reload sweeps take the diagonal tile (last 128 k-steps, where wave g only has 16 (g + 1) steps of work)
+            // OUT of the lock-step LDS pipeline: see below.  The generating sweep keeps it in (its fragments are
+            // not in the scratch image yet).
+            const int nchunks = (GEN ? nk4 : ib * WT_K4) / VAR_CH;
             for (int ch = 0; ch < nchunks; ++ch) {
                 const int cur = ch & 1;
                 const bool more = (ch + 1 < nchunks);
@@ -366,6 +374,38 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlan pl, cons
                     else if (sub + 1 < VAR_SUBS) b_nxt = *reinterpret_cast<const d4*>(Bs(cur, (sub + 1) * VAR_SUB));
                 }
                 if (GPT_ABL != 1) __syncthreads();
+            }
+            if (!GEN && GPT_ABL != 3) {
+                // Diagonal tile of a reload sweep, barrier-free: every wave runs its own 16 (g + 1) k-steps with A from
+                // Wf and B straight from the scratch image (both one MFMA block ahead; program order pinned with
+                // sched_barrier so hipcc keeps the loads away from their first use).  No lock-step, so the waves with
+                // g and 7 - g that share a SIMD add up to the same work on every SIMD: the tile costs 0.56 of a full one
+                // instead of 0.75.
+                const int kd0 = ib * WT_K4;                              // first k-step of the diagonal tile
+                const int limit = 16 * (g + 1);                          // even
+                const d2* ap = wbase + (S_ib + kd0) * STEP_D2;
+                const d2* bp = bimg + (size_t)kd0 * 128;
+                auto ldA = [&](d2 (&a)[2], const int k) {
+                    const int kk = k < limit ? k : limit - 1;            // clamped: redundant, in bounds
+                    a[0] = ap[(size_t)kk * STEP_D2]; a[1] = ap[(size_t)kk * STEP_D2 + 64];
+                };
+                auto ldB = [&](d2 (&b)[2], const int k) {
+                    const int kk = k < limit ? k : limit - 1;
+                    b[0] = bp[(size_t)kk * 128]; b[1] = bp[(size_t)kk * 128 + 1];
+                };
+                d2 a0[2], a1[2], b0[2], b1[2];
+                ldA(a0, 0); ldA(a1, 1); ldB(b0, 0);
+                for (int k4 = 0; k4 < limit; k4 += 2) {
+                    ldB(b1, k4 + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    { const d4 bb = d4{b0[0][0], b0[0][1], b0[1][0], b0[1][1]}; GPT_MFMA16(acc, a0[0], a0[1], bb); }
+                    __builtin_amdgcn_sched_barrier(0);
+                    ldA(a0, k4 + 2); ldB(b0, k4 + 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    { const d4 bb = d4{b1[0][0], b1[0][1], b1[1][0], b1[1][1]}; GPT_MFMA16(acc, a1[0], a1[1], bb); }
+                    __builtin_amdgcn_sched_barrier(0);
+                    ldA(a1, k4 + 3);
+                }
             }
             // i-block finished: fold this wave's 64 rows of V into the per-column sums
 #pragma unroll
