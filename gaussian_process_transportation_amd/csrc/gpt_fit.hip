@@ -164,6 +164,252 @@ __global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ K, doub
 }
 
 // =====================================================================================
+// One step of the panel factorisation (left-looking inside an outer panel of `OB` columns).
+// Workgroup b of step kb owns block row r = kb + b (b = 0: the diagonal block itself).  Every workgroup
+//   1. rebuilds the diagonal block  D = A[kb,kb] - sum_j L[kb,j] L[kb,j]^T  over the panel's earlier block
+//      columns j in [p0, kb) (MFMA) and factors it — redundantly, so that a step is ONE launch with no
+//      dependency between workgroups (the serial chain of the factorisation is launches, not flops);
+//   2. does the same lazy update for its own block  B = A[r,kb] - sum_j L[r,j] L[kb,j]^T, solves
+//      L[r,kb] = B L11^-T by substitution (no explicit inverse on the chain) and writes it in place.
+// Nobody writes A[kb,kb] here: workgroup 0 parks L11 in the diagonal block of W, where k_potrf_finish
+// later turns it into inv(L11) and copies L11 into K.  So every block a workgroup reads is either
+// final (written by an earlier launch) or its own.
+// Factor scheme as k_potrf_diag: thread 4*row+q keeps the row's columns q+4m in registers, one barrier per
+// column; pivots' square roots are taken after the loop (the updates only need 1/d).
+// =====================================================================================
+constexpr int PS = NB + 2;   // [row][k] LDS stride of the MFMA operand images (conflict-free ds_read_b64 fragments)
+
+template <int Q>
+__device__ __forceinline__ double quad_bcast(double v) {
+    constexpr int ctrl = Q | (Q << 2) | (Q << 4) | (Q << 6);
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, ctrl, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, ctrl, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+// value of lane `src` (wave-uniform index) as a scalar
+__device__ __forceinline__ double lane_value(double v, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
+__global__ __launch_bounds__(256) void k_potrf_step(double* __restrict__ K, double* __restrict__ W, int NP, int kb, int p0,
+                                                    int* __restrict__ info) {
+    __shared__ double colb[2][NB], dinv[NB];
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* Ab = smem;               // L[r,j] image [NB][PS]; later the block B / X, stride DS
+    double* Bb = smem + NB * PS;     // L[kb,j] image [NB][PS]; later D, then L11, stride DS
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int lc = lane & 15, lk = lane >> 4;
+    const int b = blockIdx.x;
+    const bool panel = b > 0;
+    const size_t k0 = (size_t)kb * NB, r0 = (size_t)(kb + b) * NB;
+
+    // ---- lazy update of D (tile row w) and of the own block, accumulators seeded with A ------------------
+    // global loads run one block ahead of the MFMAs: [row t>>2][16 k from (t&3)*16] of L[kb,j] and L[r,j]
+    const int rr = t >> 2, h = (t & 3) * 16;
+    d2 pfB[8], pfA[8];
+    auto fetch = [&](int j) {
+        const d2* srcB = reinterpret_cast<const d2*>(K + (k0 + rr) * NP + (size_t)j * NB + h);
+        const d2* srcA = reinterpret_cast<const d2*>(K + (r0 + rr) * NP + (size_t)j * NB + h);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) pfB[u] = srcB[u];
+        if (panel) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) pfA[u] = srcA[u];
+        }
+    };
+    if (p0 < kb) fetch(p0);
+    d4 accD[4], accB[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const size_t i = 16 * w + lk + 4 * e, col = k0 + 16 * c + lc;
+            accD[c][e] = K[(k0 + i) * NP + col];
+            accB[c][e] = panel ? K[(r0 + i) * NP + col] : 0.0;
+        }
+    for (int j = p0; j < kb; ++j) {
+        {
+            d2* dstB = reinterpret_cast<d2*>(&Bb[rr * PS + h]);
+            d2* dstA = reinterpret_cast<d2*>(&Ab[rr * PS + h]);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) dstB[u] = pfB[u];
+            if (panel) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) dstA[u] = pfA[u];
+            }
+        }
+        __syncthreads();
+        if (j + 1 < kb) fetch(j + 1);
+        if (panel) {
+#pragma unroll
+            for (int s4 = 0; s4 < NB / 4; ++s4) {
+                const double aD = -Bb[(16 * w + lc) * PS + 4 * s4 + lk];
+                const double aB = -Ab[(16 * w + lc) * PS + 4 * s4 + lk];
+                double bb[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) bb[c] = Bb[(16 * c + lc) * PS + 4 * s4 + lk];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    accD[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(aD, bb[c], accD[c], 0, 0, 0);
+                    accB[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(aB, bb[c], accB[c], 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int s4 = 0; s4 < NB / 4; ++s4) {
+                const double aD = -Bb[(16 * w + lc) * PS + 4 * s4 + lk];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    accD[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(aD, Bb[(16 * c + lc) * PS + 4 * s4 + lk], accD[c], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = 16 * w + lk + 4 * e, col = 16 * c + lc;
+            Bb[i * DS + col] = accD[c][e];
+            Ab[i * DS + col] = accB[c][e];
+        }
+    __syncthreads();
+
+    // ---- factor D: lane = row, wave w keeps the row's columns w + 4m in registers.  Column j is published by its
+    // wave through LDS (one barrier per column); every wave reads it back once (lane l <- a[l][j]) and takes the
+    // pivot and the multipliers a[c][j] from there as scalars (v_readlane), so the update is 2 readlanes + 1 FMA
+    // per element with no further LDS traffic:  a[row][c] -= a[row][j] a[c][j] / a[j][j].
+    double a[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) a[m] = Bb[lane * DS + w + 4 * m];
+    double dreg = 1.0;               // lane j ends up with pivot j
+    const int rot = (lane + w) & 63;
+    bool bad_seen = false;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int ow = j & 3, om = j >> 2;
+        if (w == ow) colb[j & 1][lane] = a[om];
+        __syncthreads();
+        const double cr = colb[j & 1][lane];
+        const double crot = colb[j & 1][rot];        // lane 4m <- a[w + 4m][j]: compile-time readlane indices
+        double d = lane_value(cr, j);
+        if (!(d > 0.0)) {            // also catches NaN; uniform over the workgroup (and over the grid)
+            if (b == 0 && t == 0 && !bad_seen) atomicCAS(info, 0, (int)k0 + j + 1);
+            bad_seen = true;
+            d = 1.0;
+        }
+        if (lane == j) dreg = d;
+        // 1/d by v_rcp_f64 + two Newton steps (<= 2 ulp) instead of the ~14-instruction IEEE division chain
+        double rinv = __builtin_amdgcn_rcp(d);
+        rinv = fma(fma(-d, rinv, 1.0), rinv, rinv);
+        rinv = fma(fma(-d, rinv, 1.0), rinv, rinv);
+        const double f = (lane > j) ? cr * rinv : 0.0;
+#pragma unroll
+        for (int m = om; m < 16; ++m) {
+            double sc = lane_value(crot, 4 * m);
+            if (m == om) sc = (w > ow) ? sc : 0.0;
+            a[m] = fma(-f, sc, a[m]);
+        }
+    }
+    const double dsqv = sqrt(dreg), dinvv = 1.0 / dsqv;     // lane l: sqrt / inverse sqrt of pivot l
+    if (w == 0) dinv[lane] = dinvv;
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        const int c = w + 4 * m;
+        const double dc = dinv[c];
+        Bb[lane * DS + c] = (c < lane) ? a[m] * dc : ((c == lane) ? dsqv : 0.0);      // L11
+    }
+    __syncthreads();
+    if (!panel) {                                                // parked in W until k_potrf_finish
+        for (int e = t; e < NB * NB; e += 256) {
+            const int r = e / NB, c = e % NB;
+            W[(k0 + r) * NP + k0 + c] = Bb[r * DS + c];
+        }
+        return;
+    }
+
+    // ---- X = B L11^-T: thread (row, q) keeps x[row][q+4m]; column j's owner scales, the quad shares it ----
+    const int row = t >> 2, q = t & 3;
+    double x[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) x[m] = Ab[row * DS + q + 4 * m];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int oq = j & 3, om = j >> 2;
+        double lcol[16];
+#pragma unroll
+        for (int m = om; m < 16; ++m) lcol[m] = Bb[(q + 4 * m) * DS + j];
+        const double xo = x[om] * dinv[j];
+        double xj;
+        switch (oq) {
+            case 0: xj = quad_bcast<0>(xo); break;
+            case 1: xj = quad_bcast<1>(xo); break;
+            case 2: xj = quad_bcast<2>(xo); break;
+            default: xj = quad_bcast<3>(xo); break;
+        }
+        if (q <= oq) lcol[om] = 0.0;
+        x[om] = (q == oq) ? xj : x[om];
+#pragma unroll
+        for (int m = om; m < 16; ++m) x[m] = fma(-xj, lcol[m], x[m]);
+    }
+#pragma unroll
+    for (int m = 0; m < 16; ++m) K[(r0 + row) * NP + k0 + q + 4 * m] = x[m];
+}
+
+// After the last step: for every diagonal block, move the parked L11 from W into K (zeros above the diagonal)
+// and leave inv(L11) in W (the seed of launch_trinv).  One workgroup per block, all blocks in one launch.
+__global__ __launch_bounds__(256) void k_potrf_finish(double* __restrict__ K, double* __restrict__ W, int NP) {
+    __shared__ double dinv[NB];
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* Ls = smem;                      // L11, row-major [NB][DS]
+    double* Xs = smem + NB * DS;            // L11^-1
+    const int t = threadIdx.x;
+    const size_t k0 = (size_t)blockIdx.x * NB;
+    for (int e = t; e < NB * NB; e += 256) {
+        const int r = e / NB, c = e % NB;
+        const double v = (c <= r) ? W[(k0 + r) * NP + k0 + c] : 0.0;
+        Ls[r * DS + c] = v;
+        K[(k0 + r) * NP + k0 + c] = v;
+    }
+    __syncthreads();
+    if (t < NB) dinv[t] = 1.0 / Ls[t * DS + t];
+    __syncthreads();
+    // lanes 4c..4c+3 own column c of X = L^-1; lane p keeps x[k], k = p (mod 4), in registers and sums those
+    // terms of each row's dot product; the row result is shared by two lane exchanges
+    {
+        const int c = t >> 2, p = t & 3;
+        double xr[16];
+#pragma unroll
+        for (int m = 0; m < 16; ++m) xr[m] = 0.0;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            double sp = 0.0;
+#pragma unroll
+            for (int m = 0; m < (i + 3) / 4; ++m) {
+                const int k = p + 4 * m;
+                if (k < i) sp = fma(Ls[i * DS + k], xr[m], sp);       // x[k] = 0 for k < c
+            }
+            sp += __shfl_xor(sp, 1);
+            sp += __shfl_xor(sp, 2);
+            const double x = (i >= c) ? (((i == c) ? 1.0 : 0.0) - sp) * dinv[i] : 0.0;
+            if (p == (i & 3)) xr[i >> 2] = x;
+            if (p == 0) Xs[i * DS + c] = x;
+        }
+    }
+    __syncthreads();
+    for (int e = t; e < NB * NB; e += 256) {
+        const int r = e / NB, c = e % NB;
+        W[(k0 + r) * NP + k0 + c] = Xs[r * DS + c];
+    }
+}
+
+// =====================================================================================
 // Generic fp64 MFMA GEMM, 128x128 output tile per workgroup (4 waves, 2x2, 64x64 each),
 // K consumed in LDS-staged chunks of 32:  C = alpha * A * op(B) + beta * C.
 //   BT = true : op(B) = B^T, B stored [n][k] row-major (SYRK / TRSM-by-inverse)
@@ -190,18 +436,47 @@ struct GemmArgs {
 constexpr int GA_S = 34;     // [row][k] stride
 constexpr int GB_S = 144;    // [k][n] stride
 
+// Tile -> workgroup mapping.  Workgroups are dealt round-robin over the 8 XCDs (linear id mod 8) and each XCD has
+// its own L2, so the 1-D grid is decoded as (xcd = id % 8, s = id / 8).  Tile rows of all batch entries are
+// numbered R = batch * TM + ti and dealt to the XCDs in groups of 8, boustrophedon (0..7, 7..0, ...), so that
+// triangular problems stay balanced between XCDs; an XCD then walks its G rows x TN columns in the order that
+// starts the longest tiles first (greedy longest-processing-time: the K range of a tile shrinks with tj when B is
+// triangular, grows with ti when A is, shrinks with ti for W^T W), and the ~64 workgroups it runs at a time share
+// a few row and column panels in that XCD's L2.
 // AT = true: A is given transposed, A(i,k) = Amem[k*lda + i] (used for K^-1 = W^T W).
 template <bool BT, bool AT = false>
-__global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
+__global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g, int TM, int TN, int G, int fold_tm) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* As = smem;                // [128][GA_S]
-    double* Bs = smem + 128 * GA_S;   // BT: [128][GA_S]   else: [32][GB_S]
-    const int b = blockIdx.z;
+    double* As = smem;                                       // [128][GA_S]   (AT: [32][GB_S])
+    double* Bs = smem + (AT ? 32 * GB_S : 128 * GA_S);       // BT: [128][GA_S]   else: [32][GB_S]
+    int b, ti, tj;
+    {
+        const int xcd = blockIdx.x & 7, sidx = blockIdx.x >> 3;
+        int gi;
+        if (g.a_lower)        { gi = G - 1 - sidx / TN; tj = sidx % TN; }     // long rows first
+        else if (g.k_from_ij) { gi = sidx / TN;         tj = sidx % TN; }     // short offsets first
+        else                  { tj = sidx / G;          gi = sidx % G; }      // column by column
+        const int R = 8 * gi + ((gi & 1) ? 7 - xcd : xcd);
+        b = R / TM;
+        ti = R - b * TM;
+        if (b >= g.nbatch) return;
+        if (fold_tm) {
+            // square lower-triangular tile set (fold_tm x fold_tm, tj <= ti) folded into a (fold_tm+1)/2 x (fold_tm+1)
+            // rectangle: row u carries tile row u (u+1 tiles) and tile row fold_tm-1-u (fold_tm-u tiles) — no empty
+            // workgroups and the same number of tiles in every row
+            const int u = ti, v = tj;
+            if (v <= u) { ti = u; tj = v; }
+            else {
+                ti = fold_tm - 1 - u; tj = v - u - 1;
+                if (ti == u) return;                        // odd fold_tm: the middle row is covered by the first half
+            }
+        }
+    }
     const bool last = (b == g.nbatch - 1);
     const int M = last ? g.M_last : g.M;
     const int K = last ? g.K_last : g.K;
     const int N = g.N;
-    const int i0 = blockIdx.y * 128, j0 = blockIdx.x * 128;
+    const int i0 = ti * 128, j0 = tj * 128;
     if (i0 >= M || j0 >= N) return;
     if (g.lower_only && j0 > i0) return;
     const double* A = g.A + (size_t)b * g.sA;
@@ -215,53 +490,73 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
     const int wr = w >> 1, wc = w & 1;
     const int lc = lane & 15, lk = lane >> 4;
     const bool active = (i0 + 64 * wr < M) && (j0 + 64 * wc < N) && !(g.lower_only && i0 == j0 && wc > wr);
+    // beta != 0: the accumulators start from (beta/alpha) C, so the read of C flies under the first chunk's
+    // staging instead of sitting in the epilogue (the rank-k updates of the Cholesky have only 4-8 chunks per tile)
     d4 acc[4][4];
+    const double cscale = g.beta != 0.0 ? g.beta / g.alpha : 0.0;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc[r][c] = d4{0, 0, 0, 0};
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = i0 + 64 * wr + 16 * r + lk + 4 * e;
+                const int col = j0 + 64 * wc + 16 * c + lc;
+                acc[r][c][e] = (active && cscale != 0.0) ? cscale * C[(size_t)row * g.ldc + col] : 0.0;
+            }
 
-    for (int kc = kbeg; kc < kend; kc += 32) {
-        if (!AT) {   // A chunk: 128 rows x 32 k; thread -> row t>>1, 16 consecutive k
-            const int r = t >> 1, h = (t & 1) * 16;
-            const bool ok = (i0 + r) < M;
-            const d2* src = reinterpret_cast<const d2*>(A + (size_t)(i0 + r) * g.lda + kc + h);
-            d2* dst = reinterpret_cast<d2*>(&As[r * GA_S + h]);
+    // global -> registers one chunk ahead of the MFMAs (the loads of chunk k+1 fly under the MFMAs of chunk k),
+    // registers -> LDS between two barriers.  Every wave-level load covers whole 128-B lines:
+    //   [row][k] sources (A, and B when BT): 16 lanes x 16 B along k, 4 rows per instruction, 8 instructions;
+    //   [k][n] sources (B when !BT, A when AT): 64 lanes x 16 B along n/i, one k row per instruction.
+    const int rk_r = t >> 4, rk_k = (t & 15) * 2;        // [row][k] staging: row rk_r + 16u, k offset rk_k
+    const int kn_k = t >> 6, kn_n = (t & 63) * 2;        // [k][n]  staging: k row kn_k + 4u, n offset kn_n
+    // uniform (scalar) base per instruction + one per-lane 32-bit offset per operand keeps the address registers few
+    const int offA = AT ? kn_k * (int)g.lda + kn_n : rk_r * (int)g.lda + rk_k;
+    const int offB = BT ? rk_r * (int)g.ldb + rk_k : kn_k * (int)g.ldb + kn_n;
+    const bool okA_n = (i0 + kn_n) < M, okB_n = (j0 + kn_n) < N;     // all dims are multiples of 64
+    d2 pa[8], pb[8];
+    auto fetch = [&](int kc) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) dst[u] = ok ? src[u] : d2{0, 0};
-        } else {     // transposed source: thread -> k row t>>3, 16 consecutive i (coalesced), scattered into [i][k]
-            const int kr = t >> 3, sg = (t & 7) * 16;
-            const bool ok = (i0 + sg) < M;
-            const d2* src = reinterpret_cast<const d2*>(A + (size_t)(kc + kr) * g.lda + i0 + sg);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const d2 v = ok ? src[u] : d2{0, 0};
-                As[(sg + 2 * u) * GA_S + kr] = v[0];
-                As[(sg + 2 * u + 1) * GA_S + kr] = v[1];
+        for (int u = 0; u < 8; ++u) {
+            if (!AT) {
+                const double* base = A + (size_t)(i0 + 16 * u) * g.lda + kc;
+                pa[u] = (i0 + 16 * u) < M ? *reinterpret_cast<const d2*>(base + offA) : d2{0, 0};
+            } else {
+                const double* base = A + (size_t)(kc + 4 * u) * g.lda + i0;
+                pa[u] = okA_n ? *reinterpret_cast<const d2*>(base + offA) : d2{0, 0};
+            }
+            if (BT) {
+                const double* base = B + (size_t)(j0 + 16 * u) * g.ldb + kc;
+                pb[u] = (j0 + 16 * u) < N ? *reinterpret_cast<const d2*>(base + offB) : d2{0, 0};
+            } else {
+                const double* base = B + (size_t)(kc + 4 * u) * g.ldb + j0;
+                pb[u] = okB_n ? *reinterpret_cast<const d2*>(base + offB) : d2{0, 0};
             }
         }
-        if (BT) {
-            const int r = t >> 1, h = (t & 1) * 16;
-            const bool ok = (j0 + r) < N;
-            const d2* src = reinterpret_cast<const d2*>(B + (size_t)(j0 + r) * g.ldb + kc + h);
-            d2* dst = reinterpret_cast<d2*>(&Bs[r * GA_S + h]);
+    };
+    auto stage = [&]() {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) dst[u] = ok ? src[u] : d2{0, 0};
-        } else {
-            const int kr = t >> 3, sg = (t & 7) * 16;
-            const bool ok = (j0 + sg) < N;      // N multiple of 64 and sg multiple of 16
-            const d2* src = reinterpret_cast<const d2*>(B + (size_t)(kc + kr) * g.ldb + j0 + sg);
-            d2* dst = reinterpret_cast<d2*>(&Bs[kr * GB_S + sg]);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) dst[u] = ok ? src[u] : d2{0, 0};
+        for (int u = 0; u < 8; ++u) {
+            if (!AT) *reinterpret_cast<d2*>(&As[(rk_r + 16 * u) * GA_S + rk_k]) = pa[u];
+            else     *reinterpret_cast<d2*>(&As[(kn_k + 4 * u) * GB_S + kn_n]) = pa[u];
+            if (BT)  *reinterpret_cast<d2*>(&Bs[(rk_r + 16 * u) * GA_S + rk_k]) = pb[u];
+            else     *reinterpret_cast<d2*>(&Bs[(kn_k + 4 * u) * GB_S + kn_n]) = pb[u];
         }
+    };
+    if (kbeg < kend) fetch(kbeg);
+    for (int kc = kbeg; kc < kend; kc += 32) {
+        stage();
         __syncthreads();
+        if (kc + 32 < kend) fetch(kc + 32);
         if (active) {
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
                 double a[4], bb[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) a[r] = As[(64 * wr + 16 * r + lc) * GA_S + 4 * s + lk];
+                for (int r = 0; r < 4; ++r)
+                    a[r] = AT ? As[(4 * s + lk) * GB_S + 64 * wr + 16 * r + lc]
+                              : As[(64 * wr + 16 * r + lc) * GA_S + 4 * s + lk];
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
                     bb[c] = BT ? Bs[(64 * wc + 16 * c + lc) * GA_S + 4 * s + lk]
@@ -276,7 +571,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
         __syncthreads();
     }
     if (!active) return;
-    const double alpha = g.alpha, beta = g.beta;
+    const double alpha = g.alpha;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -285,24 +580,25 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
             for (int e = 0; e < 4; ++e) {
                 const int row = i0 + 64 * wr + 16 * r + lk + 4 * e;
                 const int col = j0 + 64 * wc + 16 * c + lc;
-                double* p = C + (size_t)row * g.ldc + col;
-                double v = alpha * acc[r][c][e];
-                if (beta != 0.0) v += beta * (*p);
-                *p = v;
+                C[(size_t)row * g.ldc + col] = alpha * acc[r][c][e];
             }
 }
 
 template <bool BT, bool AT = false>
 static void launch_gemm(hipStream_t s, const GemmArgs& g) {
     const int Mmax = g.M > g.M_last ? g.M : g.M_last;
-    dim3 grid((g.N + 127) / 128, (Mmax + 127) / 128, g.nbatch);
-    constexpr size_t lds = (size_t)(128 * GA_S + (BT ? 128 * GA_S : 32 * GB_S)) * sizeof(double);
+    int TM = (Mmax + 127) / 128, TN = (g.N + 127) / 128;
+    int fold_tm = 0;
+    if (g.lower_only && g.nbatch == 1 && TM == TN && TM > 1) { fold_tm = TM; TM = (fold_tm + 1) / 2; TN = fold_tm + 1; }
+    const int G = (g.nbatch * TM + 7) / 8;          // tile rows (over all batch entries) per XCD
+    dim3 grid(8 * G * TN);
+    constexpr size_t lds = (size_t)((AT ? 32 * GB_S : 128 * GA_S) + (BT ? 128 * GA_S : 32 * GB_S)) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<BT, AT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_gemm<BT, AT>), grid, dim3(256), lds, s, g);
+    hipLaunchKernelGGL((k_gemm<BT, AT>), grid, dim3(256), lds, s, g, TM, TN, G, fold_tm);
 }
 
 // =====================================================================================
@@ -324,7 +620,11 @@ struct PotrfStreams {
 static PotrfStreams& potrf_streams() {
     static PotrfStreams ps;
     if (!ps.side) {
-        ps.ok = hipStreamCreateWithFlags(&ps.side, hipStreamNonBlocking) == hipSuccess;
+        // lowest priority: the bulk update only has to keep up; the step / panel launches on the caller's stream are
+        // the serial chain and should get compute units first whenever both have workgroups waiting
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        ps.ok = hipStreamCreateWithPriority(&ps.side, hipStreamNonBlocking, least) == hipSuccess;
         for (int i = 0; i < 2 && ps.ok; ++i)
             ps.ok = hipEventCreateWithFlags(&ps.panel_done[i], hipEventDisableTiming) == hipSuccess &&
                     hipEventCreateWithFlags(&ps.bulk_done[i], hipEventDisableTiming) == hipSuccess;
@@ -332,7 +632,7 @@ static PotrfStreams& potrf_streams() {
     return ps;
 }
 
-void launch_potrf(hipStream_t s, double* K, double* W, int NP, int* info) {
+static void launch_potrf_legacy(hipStream_t s, double* K, double* W, int NP, int* info) {
     const int nb = NP / NB;
     constexpr size_t diag_lds = (size_t)(2 * NB * DS) * sizeof(double);
     static bool attr_set = false;
@@ -386,6 +686,77 @@ void launch_potrf(hipStream_t s, double* K, double* W, int NP, int* info) {
         }
     }
     if (bulk_pending) hipStreamWaitEvent(s, ps.bulk_done[pending_slot], 0);
+}
+
+// Two-level blocking: panels of OB = `ob_blocks` x NB columns are factored by k_potrf_step (one launch per NB
+// columns, left-looking inside the panel); the trailing matrix then gets ONE rank-OB update per panel (MFMA
+// GEMM on the block lower triangle), split as above into the next panel's columns (main stream) and the
+// rest (side stream, underneath the next panel's step launches).
+static int potrf_outer_blocks() {
+    static int ob = 0;
+    if (!ob) {
+        ob = 4;
+        if (const char* e = getenv("GPT_POTRF_OB")) { const int v = atoi(e) / NB; if (v >= 1 && v <= 8) ob = v; }
+    }
+    return ob;
+}
+
+void launch_potrf(hipStream_t s, double* K, double* W, int NP, int* info) {
+    static const bool legacy = getenv("GPT_POTRF_LEGACY") != nullptr;
+    if (legacy) { launch_potrf_legacy(s, K, W, NP, info); return; }
+    const int nb = NP / NB;
+    const int ob = potrf_outer_blocks();
+    constexpr size_t step_lds = (size_t)(2 * NB * PS) * sizeof(double);
+    constexpr size_t fin_lds = (size_t)(2 * NB * DS) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_step), hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_finish), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fin_lds);
+        attr_set = true;
+    }
+    PotrfStreams& ps = potrf_streams();
+    const bool lookahead = ps.ok && nb > 2 * ob;
+    bool bulk_pending = false;
+    int pending_slot = 0, slot = 0;
+    for (int p0 = 0; p0 < nb; p0 += ob) {
+        const int pend = p0 + ob < nb ? p0 + ob : nb;
+        for (int kb = p0; kb < pend; ++kb)
+            hipLaunchKernelGGL(k_potrf_step, dim3(nb - kb), dim3(256), step_lds, s, K, W, NP, kb, p0, info);
+        const int r0 = pend * NB, kw = (pend - p0) * NB;
+        const int rem = NP - r0;
+        if (rem <= 0) break;
+        // trailing update A22 -= L21 L21^T with the whole panel (K = kw): the next panel's columns first
+        if (bulk_pending) hipStreamWaitEvent(s, ps.bulk_done[pending_slot], 0);   // bulk(P-1) also wrote these columns
+        bulk_pending = false;
+        static const bool single_update = getenv("GPT_POTRF_LOOKAHEAD") == nullptr;
+        const int nw = single_update ? rem : (rem < ob * NB ? rem : ob * NB);
+        GemmArgs c{};
+        c.A = K + (size_t)r0 * NP + (size_t)p0 * NB; c.lda = NP;
+        c.B = c.A; c.ldb = NP;
+        c.C = K + (size_t)r0 * NP + r0; c.ldc = NP;
+        c.M = c.M_last = rem; c.N = nw; c.K = c.K_last = kw; c.nbatch = 1;
+        c.alpha = -1.0; c.beta = 1.0; c.lower_only = 1;
+        launch_gemm<true>(s, c);
+        const int rem2 = rem - nw;
+        if (rem2 <= 0) continue;
+        GemmArgs u{};
+        u.A = K + (size_t)(r0 + nw) * NP + (size_t)p0 * NB; u.lda = NP;
+        u.B = u.A; u.ldb = NP;
+        u.C = K + (size_t)(r0 + nw) * NP + (r0 + nw); u.ldc = NP;
+        u.M = u.M_last = rem2; u.N = rem2; u.K = u.K_last = kw; u.nbatch = 1;
+        u.alpha = -1.0; u.beta = 1.0; u.lower_only = 1;
+        if (lookahead) {
+            hipEventRecord(ps.panel_done[slot], s);                 // panel P and the next panel's columns are done here
+            hipStreamWaitEvent(ps.side, ps.panel_done[slot], 0);
+            launch_gemm<true>(ps.side, u);
+            hipEventRecord(ps.bulk_done[slot], ps.side);
+            bulk_pending = true; pending_slot = slot; slot ^= 1;
+        } else {
+            launch_gemm<true>(s, u);
+        }
+    }
+    if (bulk_pending) hipStreamWaitEvent(s, ps.bulk_done[pending_slot], 0);
+    hipLaunchKernelGGL(k_potrf_finish, dim3(nb), dim3(256), fin_lds, s, K, W, NP);
 }
 
 // =====================================================================================

@@ -1,0 +1,38 @@
+"""Fit-phase timings (device events of gpt_fit_timings) and a factor check against numpy, per N.
+usage: python tools/fit_timing.py [N ...]   (env GPT_POTRF_LEGACY / GPT_POTRF_OB select the Cholesky variant)"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gaussian_process_transportation_amd import _lib  # noqa: E402
+
+Ns = [int(a) for a in sys.argv[1:]] or [1024, 2500, 8192]
+tag = "legacy" if os.environ.get("GPT_POTRF_LEGACY") else "OB=" + os.environ.get("GPT_POTRF_OB", "256")
+for N in Ns:
+    rng = np.random.default_rng(0)
+    X = rng.uniform(0, 1, (N, 3))
+    Y = 0.05 * np.sin(4 * X) + 0.01 * rng.standard_normal((N, 3))
+    ls = np.array([0.1, 0.1, 0.1])
+    h = _lib.Handle(0)
+    best = None
+    for rep in range(4):
+        t0 = time.perf_counter()
+        h.fit(X, Y, ls, 0.1, 1e-4, 1e-10)
+        wall = (time.perf_counter() - t0) * 1e3
+        t = h.fit_timings()
+        if best is None or t["total"] < best[0]["total"]:
+            best = (t, wall)
+    t, wall = best
+    msg = f"[{tag}] N={N}: " + "  ".join(f"{k} {v:.2f}" for k, v in t.items()) + f"  (host wall {wall:.1f} ms)"
+    if N <= 2500:      # factor against LAPACK
+        d = X[:, None, :] - X[None, :, :]
+        Kref = 0.1 * np.exp(-0.5 * (d * d).sum(-1) / 0.01) + (1e-4 + 1e-10) * np.eye(N)
+        Lref = np.linalg.cholesky(Kref)
+        L, alpha = h.export(want_L=True)
+        err = np.abs(L - Lref).max() / np.abs(Lref).max()
+        msg += f"  max|L-L_lapack|/max|L| = {err:.2e}"
+    print(msg, flush=True)
+    del h
