@@ -8,6 +8,8 @@
 // kept as its triangular factor W = L^-1 so that k^T K^-1 k = |W k|^2).
 #include "gpt_common.h"
 #include "gpt_exp.h"
+#include <type_traits>
+#include <utility>
 
 namespace gpt {
 
@@ -70,98 +72,7 @@ void launch_add_lower(hipStream_t s, double* K, const double* S, int N, int NP) 
     hipLaunchKernelGGL(k_add_lower, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, K, S, N, NP);
 }
 
-// =====================================================================================
-// Diagonal block: unblocked Cholesky of one NB x NB block in LDS + its triangular inverse.
-// One workgroup.  Writes L_kk into K (zeros above the diagonal) and L_kk^-1 into W.
-// A non-positive (or NaN) pivot records 1-based row index in *info (first failure wins)
-// and substitutes 1 so the kernel chain terminates without NaN storms.
-// =====================================================================================
-constexpr int DS = NB + 1;   // LDS row stride (doubles)
-
-// Thread t = 4*row + q holds the row's elements of columns c = q + 4m (m = 0..15) in registers for the whole
-// factorisation; at step j the owners of column j publish it through a double-buffered 64-entry LDS vector
-// (one barrier per step), everybody updates its registers: a[c] -= a[row][j] a[c][j] / a[j][j].
-// The inverse is a forward substitution with 4 lanes per column sharing each dot product.
-__global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ K, double* __restrict__ W, int NP, int kb,
-                                                    int* __restrict__ info) {
-    __shared__ double colb[2][NB];
-    __shared__ double dsq[NB], dinv[NB];
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* Ls = smem;                      // L, row-major [NB][DS]
-    double* Xs = smem + NB * DS;            // L^-1, row-major [NB][DS]
-    const int t = threadIdx.x;
-    const int row = t >> 2, q = t & 3;
-    const int k0 = kb * NB;
-    double a[16];
-#pragma unroll
-    for (int m = 0; m < 16; ++m) {
-        const int c = q + 4 * m;
-        a[m] = (c <= row) ? K[(size_t)(k0 + row) * NP + k0 + c] : 0.0;
-    }
-    bool bad_seen = false;
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        if (q == (j & 3)) colb[j & 1][row] = a[j >> 2];
-        __syncthreads();
-        double d = colb[j & 1][j];
-        if (!(d > 0.0)) {            // also catches NaN; uniform over the workgroup
-            if (t == 0 && !bad_seen) atomicCAS(info, 0, k0 + j + 1);
-            bad_seen = true;
-            d = 1.0;
-        }
-        if (t == 0) { const double sd = sqrt(d); dsq[j] = sd; dinv[j] = 1.0 / sd; }
-        if (row > j) {
-            // 1/d by v_rcp_f64 + two Newton steps (<= 2 ulp) instead of the ~14-instruction IEEE division chain
-            double rinv = __builtin_amdgcn_rcp(d);
-            rinv = fma(fma(-d, rinv, 1.0), rinv, rinv);
-            rinv = fma(fma(-d, rinv, 1.0), rinv, rinv);
-            const double f = colb[j & 1][row] * rinv;
-#pragma unroll
-            for (int m = (j >> 2); m < 16; ++m) {
-                const int c = q + 4 * m;
-                if (c > j && c <= row) a[m] -= f * colb[j & 1][c];
-            }
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int m = 0; m < 16; ++m) {
-        const int c = q + 4 * m;
-        double v = 0.0;
-        if (c < row) v = a[m] * dinv[c];
-        else if (c == row) v = dsq[row];
-        Ls[row * DS + c] = v;
-        K[(size_t)(k0 + row) * NP + k0 + c] = v;
-    }
-    __syncthreads();
-    // inverse: lanes 4c..4c+3 own column c of X = L^-1; lane p keeps x[k], k = p (mod 4), in registers and sums
-    // those terms of each row's dot product; the row result is shared by two lane exchanges
-    {
-        const int c = t >> 2, p = t & 3;
-        double xr[16];
-#pragma unroll
-        for (int m = 0; m < 16; ++m) xr[m] = 0.0;
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            double sp = 0.0;
-#pragma unroll
-            for (int m = 0; m < (i + 3) / 4; ++m) {
-                const int k = p + 4 * m;
-                if (k < i) sp = fma(Ls[i * DS + k], xr[m], sp);       // x[k] = 0 for k < c
-            }
-            sp += __shfl_xor(sp, 1);
-            sp += __shfl_xor(sp, 2);
-            const double x = (i >= c) ? (((i == c) ? 1.0 : 0.0) - sp) * dinv[i] : 0.0;
-            if (p == (i & 3)) xr[i >> 2] = x;
-            if (p == 0) Xs[i * DS + c] = x;
-        }
-    }
-    __syncthreads();
-    for (int e = t; e < NB * NB; e += 256) {
-        const int r = e / NB, c = e % NB;
-        W[(size_t)(k0 + r) * NP + k0 + c] = Xs[r * DS + c];
-    }
-}
+constexpr int DS = NB + 1;   // LDS row stride (doubles) of the NB x NB block images
 
 // =====================================================================================
 // One step of the panel factorisation (left-looking inside an outer panel of `OB` columns).
@@ -174,10 +85,16 @@ __global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ K, doub
 // Nobody writes A[kb,kb] here: workgroup 0 parks L11 in the diagonal block of W, where k_potrf_finish
 // later turns it into inv(L11) and copies L11 into K.  So every block a workgroup reads is either
 // final (written by an earlier launch) or its own.
-// Factor scheme as k_potrf_diag: thread 4*row+q keeps the row's columns q+4m in registers, one barrier per
-// column; pivots' square roots are taken after the loop (the updates only need 1/d).
+// The factor is unnormalised inside the loop (a[row][c] -= a[row][j] a[c][j] / a[j][j], one barrier per column);
+// the pivots' square roots are taken after it.
 // =====================================================================================
 constexpr int PS = NB + 2;   // [row][k] LDS stride of the MFMA operand images (conflict-free ds_read_b64 fragments)
+
+// f(integral_constant<int, 0>{}), f(integral_constant<int, 1>{}), ... : a loop the compiler cannot decline to unroll
+template <int... I, class F>
+__device__ __forceinline__ void unroll_ints(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
 
 template <int Q>
 __device__ __forceinline__ double quad_bcast(double v) {
@@ -195,16 +112,25 @@ __device__ __forceinline__ double lane_value(double v, int src) {
     return __hiloint2double(hi, lo);
 }
 
-__global__ __launch_bounds__(256) void k_potrf_step(double* __restrict__ K, double* __restrict__ W, int NP, int kb, int p0,
-                                                    int* __restrict__ info) {
-    __shared__ double colb[2][NB], dinv[NB];
-    extern __shared__ __attribute__((aligned(16))) double smem[];
+#ifdef GPT_STEP_TRACE      // tools/probes/potrf_step_probe.hip: shader-clock stamps of workgroup 1's phases
+#define GPT_TRACE_ARG , long long* trace
+#define GPT_TRACE_NULL , nullptr
+#define GPT_TRACE(i) do { if (trace && blockIdx.x == 1 && threadIdx.x == 0) trace[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define GPT_TRACE_ARG
+#define GPT_TRACE_NULL
+#define GPT_TRACE(i) do { } while (0)
+#endif
+__device__ __forceinline__ void potrf_step_body(double* __restrict__ K, double* __restrict__ W, int NP, int kb, int p0,
+                                                int* __restrict__ info, const int b, double* smem GPT_TRACE_ARG) {
+    __shared__ __attribute__((aligned(16))) double colp[2][NB];
+    __shared__ double dinv[NB];
+    GPT_TRACE(0);
     double* Ab = smem;               // L[r,j] image [NB][PS]; later the block B / X, stride DS
     double* Bb = smem + NB * PS;     // L[kb,j] image [NB][PS]; later D, then L11, stride DS
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int lc = lane & 15, lk = lane >> 4;
-    const int b = blockIdx.x;
     const bool panel = b > 0;
     const size_t k0 = (size_t)kb * NB, r0 = (size_t)(kb + b) * NB;
 
@@ -279,25 +205,35 @@ __global__ __launch_bounds__(256) void k_potrf_step(double* __restrict__ K, doub
             Ab[i * DS + col] = accB[c][e];
         }
     __syncthreads();
+    GPT_TRACE(1);
 
-    // ---- factor D: lane = row, wave w keeps the row's columns w + 4m in registers.  Column j is published by its
-    // wave through LDS (one barrier per column); every wave reads it back once (lane l <- a[l][j]) and takes the
-    // pivot and the multipliers a[c][j] from there as scalars (v_readlane), so the update is 2 readlanes + 1 FMA
-    // per element with no further LDS traffic:  a[row][c] -= a[row][j] a[c][j] / a[j][j].
+    // ---- factor D: lane = row, wave w keeps the row's columns w + 4m in registers:  a[row][c] -= a[row][j] a[c][j] / a[j][j].
+    // Column j is published through LDS in wave-major order (colp[(c&3)*16 + (c>>2)] = a[c][j]), so that after the
+    // barrier every wave fetches the multipliers of ITS columns with wave-uniform 16-byte reads, its own row's entry
+    // with one more, and the pivot with a uniform read — no cross-lane traffic.  The element of column j+1 is updated
+    // and published first; the other updates of step j run while that write is on its way to the barrier.
     double a[16];
 #pragma unroll
     for (int m = 0; m < 16; ++m) a[m] = Bb[lane * DS + w + 4 * m];
     double dreg = 1.0;               // lane j ends up with pivot j
-    const int rot = (lane + w) & 63;
+    const int self = (lane & 3) * 16 + (lane >> 2);
     bool bad_seen = false;
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        const int ow = j & 3, om = j >> 2;
-        if (w == ow) colb[j & 1][lane] = a[om];
+    if (w == 0) colp[0][self] = a[0];
+    auto factor_column = [&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        constexpr int ow = j & 3, om = j >> 2;
+        constexpr int nw = (j + 1) & 3, nm = (j + 1) >> 2;    // owner wave / register of column j+1
         __syncthreads();
-        const double cr = colb[j & 1][lane];
-        const double crot = colb[j & 1][rot];        // lane 4m <- a[w + 4m][j]: compile-time readlane indices
-        double d = lane_value(cr, j);
+        const double* col = colp[j & 1];
+        const double cr = col[self];
+        double d = col[ow * 16 + om];
+        double sc[16];
+#pragma unroll
+        for (int m = 0; m < 16; m += 2)
+            if (m + 1 >= om) {
+                const d2 v = *reinterpret_cast<const d2*>(&col[w * 16 + m]);
+                sc[m] = v[0]; sc[m + 1] = v[1];
+            }
         if (!(d > 0.0)) {            // also catches NaN; uniform over the workgroup (and over the grid)
             if (b == 0 && t == 0 && !bad_seen) atomicCAS(info, 0, (int)k0 + j + 1);
             bad_seen = true;
@@ -309,13 +245,27 @@ __global__ __launch_bounds__(256) void k_potrf_step(double* __restrict__ K, doub
         rinv = fma(fma(-d, rinv, 1.0), rinv, rinv);
         rinv = fma(fma(-d, rinv, 1.0), rinv, rinv);
         const double f = (lane > j) ? cr * rinv : 0.0;
-#pragma unroll
-        for (int m = om; m < 16; ++m) {
-            double sc = lane_value(crot, 4 * m);
-            if (m == om) sc = (w > ow) ? sc : 0.0;
-            a[m] = fma(-f, sc, a[m]);
+        if constexpr (j + 1 < NB) {
+            if (w == nw) {
+                a[nm] = fma(-f, sc[nm], a[nm]);
+                colp[(j + 1) & 1][self] = a[nm];
+            }
         }
-    }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 16; ++m)
+            if (m >= om) {
+                const double mult = (m == om && w <= ow) ? 0.0 : sc[m];
+                if (m != nm || w != nw) a[m] = fma(-f, mult, a[m]);
+            }
+        // keep step j's updates in step j (an opaque use): sunk towards their first reader they pile up hundreds of
+        // live multipliers and the kernel spills
+#pragma unroll
+        for (int m = 0; m < 16; ++m)
+            if (m >= om) asm volatile("" : "+v"(a[m]));
+    };
+    unroll_ints(std::make_integer_sequence<int, NB>{}, factor_column);
+    GPT_TRACE(2);
     const double dsqv = sqrt(dreg), dinvv = 1.0 / dsqv;     // lane l: sqrt / inverse sqrt of pivot l
     if (w == 0) dinv[lane] = dinvv;
     __syncthreads();
@@ -335,6 +285,7 @@ __global__ __launch_bounds__(256) void k_potrf_step(double* __restrict__ K, doub
     }
 
     // ---- X = B L11^-T: thread (row, q) keeps x[row][q+4m]; column j's owner scales, the quad shares it ----
+    GPT_TRACE(3);
     const int row = t >> 2, q = t & 3;
     double x[16];
 #pragma unroll
@@ -358,8 +309,20 @@ __global__ __launch_bounds__(256) void k_potrf_step(double* __restrict__ K, doub
 #pragma unroll
         for (int m = om; m < 16; ++m) x[m] = fma(-xj, lcol[m], x[m]);
     }
+    GPT_TRACE(4);
 #pragma unroll
     for (int m = 0; m < 16; ++m) K[(r0 + row) * NP + k0 + q + 4 * m] = x[m];
+    GPT_TRACE(5);
+}
+
+__global__ __launch_bounds__(256) void k_potrf_step(double* __restrict__ K, double* __restrict__ W, int NP, int kb, int p0,
+                                                    int* __restrict__ info GPT_TRACE_ARG) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+#ifdef GPT_STEP_TRACE
+    potrf_step_body(K, W, NP, kb, p0, info, blockIdx.x, smem, trace);
+#else
+    potrf_step_body(K, W, NP, kb, p0, info, blockIdx.x, smem);
+#endif
 }
 
 // After the last step: for every diagonal block, move the parked L11 from W into K (zeros above the diagonal)
@@ -445,13 +408,12 @@ constexpr int GB_S = 144;    // [k][n] stride
 // a few row and column panels in that XCD's L2.
 // AT = true: A is given transposed, A(i,k) = Amem[k*lda + i] (used for K^-1 = W^T W).
 template <bool BT, bool AT = false>
-__global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g, int TM, int TN, int G, int fold_tm) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
+__device__ __forceinline__ void gemm_tile(const GemmArgs& g, int TM, int TN, int G, int fold_tm, const int vid, double* smem) {
     double* As = smem;                                       // [128][GA_S]   (AT: [32][GB_S])
     double* Bs = smem + (AT ? 32 * GB_S : 128 * GA_S);       // BT: [128][GA_S]   else: [32][GB_S]
     int b, ti, tj;
     {
-        const int xcd = blockIdx.x & 7, sidx = blockIdx.x >> 3;
+        const int xcd = vid & 7, sidx = vid >> 3;
         int gi;
         if (g.a_lower)        { gi = G - 1 - sidx / TN; tj = sidx % TN; }     // long rows first
         else if (g.k_from_ij) { gi = sidx / TN;         tj = sidx % TN; }     // short offsets first
@@ -494,16 +456,24 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g, int TM, int TN, int
     // staging instead of sitting in the epilogue (the rank-k updates of the Cholesky have only 4-8 chunks per tile)
     d4 acc[4][4];
     const double cscale = g.beta != 0.0 ? g.beta / g.alpha : 0.0;
+    double* const ctile = C + (size_t)(i0 + 64 * wr + lk) * g.ldc + j0 + 64 * wc + lc;     // this lane's first element
+    if (active && cscale != 0.0) {          // one uniform branch, then 64 independent loads in flight together
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+            for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int row = i0 + 64 * wr + 16 * r + lk + 4 * e;
-                const int col = j0 + 64 * wc + 16 * c + lc;
-                acc[r][c][e] = (active && cscale != 0.0) ? cscale * C[(size_t)row * g.ldc + col] : 0.0;
-            }
+                for (int e = 0; e < 4; ++e) acc[r][c][e] = ctile[(size_t)(16 * r + 4 * e) * g.ldc + 16 * c];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[r][c] *= cscale;
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[r][c] = d4{0, 0, 0, 0};
+    }
 
     // global -> registers one chunk ahead of the MFMAs (the loads of chunk k+1 fly under the MFMAs of chunk k),
     // registers -> LDS between two barriers.  Every wave-level load covers whole 128-B lines:
@@ -577,21 +547,31 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g, int TM, int TN, int
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int row = i0 + 64 * wr + 16 * r + lk + 4 * e;
-                const int col = j0 + 64 * wc + 16 * c + lc;
-                C[(size_t)row * g.ldc + col] = alpha * acc[r][c][e];
-            }
+            for (int e = 0; e < 4; ++e) ctile[(size_t)(16 * r + 4 * e) * g.ldc + 16 * c] = alpha * acc[r][c][e];
+}
+
+template <bool BT, bool AT = false>
+__global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g, int TM, int TN, int G, int fold_tm) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    gemm_tile<BT, AT>(g, TM, TN, G, fold_tm, blockIdx.x, smem);
+}
+
+struct GemmGrid { int TM, TN, G, fold_tm, nvid; };
+static GemmGrid gemm_grid(const GemmArgs& g) {
+    GemmGrid q{};
+    const int Mmax = g.M > g.M_last ? g.M : g.M_last;
+    q.TM = (Mmax + 127) / 128; q.TN = (g.N + 127) / 128;
+    if (g.lower_only && g.nbatch == 1 && q.TM == q.TN && q.TM > 1) { q.fold_tm = q.TM; q.TM = (q.fold_tm + 1) / 2; q.TN = q.fold_tm + 1; }
+    q.G = (g.nbatch * q.TM + 7) / 8;            // tile rows (over all batch entries) per XCD
+    q.nvid = 8 * q.G * q.TN;
+    return q;
 }
 
 template <bool BT, bool AT = false>
 static void launch_gemm(hipStream_t s, const GemmArgs& g) {
-    const int Mmax = g.M > g.M_last ? g.M : g.M_last;
-    int TM = (Mmax + 127) / 128, TN = (g.N + 127) / 128;
-    int fold_tm = 0;
-    if (g.lower_only && g.nbatch == 1 && TM == TN && TM > 1) { fold_tm = TM; TM = (fold_tm + 1) / 2; TN = fold_tm + 1; }
-    const int G = (g.nbatch * TM + 7) / 8;          // tile rows (over all batch entries) per XCD
-    dim3 grid(8 * G * TN);
+    const GemmGrid q = gemm_grid(g);
+    const int TM = q.TM, TN = q.TN, G = q.G, fold_tm = q.fold_tm;
+    dim3 grid(q.nvid);
     constexpr size_t lds = (size_t)((AT ? 32 * GB_S : 128 * GA_S) + (BT ? 128 * GA_S : 32 * GB_S)) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
@@ -602,108 +582,23 @@ static void launch_gemm(hipStream_t s, const GemmArgs& g) {
 }
 
 // =====================================================================================
-// Blocked right-looking Cholesky (lower), NB = 64 panels:
-//   diag block (LDS, + inverse)  ->  panel  L21 = A21 * inv(L11)^T  (MFMA GEMM, in place)
-//   ->  trailing  A22 -= L21 L21^T  (MFMA GEMM on the block lower triangle).
+// Blocked Cholesky (lower), in place in K; inv(L_kk) of every diagonal block is left in W.
 // =====================================================================================
-// Look-ahead: the trailing update of step k is split into the next block column (needed by the next diagonal
-// block and panel; stays on the main stream) and the rest (side stream), so that the serial diagonal-block and
-// panel kernels of step k+1 run underneath the bulk of step k's update.  Both parts of consecutive steps touch
-// the same block column, so the column part of step k+1 waits for the bulk of step k.
-struct PotrfStreams {
-    hipStream_t side = nullptr;
-    hipEvent_t panel_done[2] = {nullptr, nullptr};   // ping-pong: panel(k) finished on the main stream
-    hipEvent_t bulk_done[2] = {nullptr, nullptr};    // bulk(k) finished on the side stream
-    bool ok = false;
-};
-
-static PotrfStreams& potrf_streams() {
-    static PotrfStreams ps;
-    if (!ps.side) {
-        // lowest priority: the bulk update only has to keep up; the step / panel launches on the caller's stream are
-        // the serial chain and should get compute units first whenever both have workgroups waiting
-        int least = 0, greatest = 0;
-        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        ps.ok = hipStreamCreateWithPriority(&ps.side, hipStreamNonBlocking, least) == hipSuccess;
-        for (int i = 0; i < 2 && ps.ok; ++i)
-            ps.ok = hipEventCreateWithFlags(&ps.panel_done[i], hipEventDisableTiming) == hipSuccess &&
-                    hipEventCreateWithFlags(&ps.bulk_done[i], hipEventDisableTiming) == hipSuccess;
-    }
-    return ps;
-}
-
-static void launch_potrf_legacy(hipStream_t s, double* K, double* W, int NP, int* info) {
-    const int nb = NP / NB;
-    constexpr size_t diag_lds = (size_t)(2 * NB * DS) * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_diag), hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_lds);
-        attr_set = true;
-    }
-    PotrfStreams& ps = potrf_streams();
-    const bool lookahead = ps.ok && nb > 4;
-    bool bulk_pending = false;
-    int pending_slot = 0;
-    for (int kb = 0; kb < nb; ++kb) {
-        hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), diag_lds, s, K, W, NP, kb, info);
-        const int r0 = (kb + 1) * NB;
-        const int rem = NP - r0;
-        if (rem <= 0) break;
-        GemmArgs p{};
-        p.A = K + (size_t)r0 * NP + kb * NB; p.lda = NP; p.sA = 0;
-        p.B = W + (size_t)kb * NB * NP + kb * NB; p.ldb = NP; p.sB = 0;   // inv(L11) stored [n][k]
-        p.C = K + (size_t)r0 * NP + kb * NB; p.ldc = NP; p.sC = 0;       // in place: each tile reads its rows before writing
-        p.M = p.M_last = rem; p.N = NB; p.K = p.K_last = NB; p.nbatch = 1;
-        p.alpha = 1.0; p.beta = 0.0;
-        launch_gemm<true>(s, p);
-        // trailing update A22 -= L21 L21^T: block column r0 .. r0+NB-1 first
-        if (bulk_pending) hipStreamWaitEvent(s, ps.bulk_done[pending_slot], 0);   // bulk(k-1) also wrote this column
-        bulk_pending = false;
-        GemmArgs c{};
-        c.A = K + (size_t)r0 * NP + kb * NB; c.lda = NP;
-        c.B = c.A; c.ldb = NP;
-        c.C = K + (size_t)r0 * NP + r0; c.ldc = NP;
-        c.M = c.M_last = rem; c.N = NB; c.K = c.K_last = NB; c.nbatch = 1;
-        c.alpha = -1.0; c.beta = 1.0; c.lower_only = 1;
-        launch_gemm<true>(s, c);
-        const int rem2 = rem - NB;
-        if (rem2 <= 0) continue;
-        GemmArgs u{};
-        u.A = K + (size_t)(r0 + NB) * NP + kb * NB; u.lda = NP;
-        u.B = u.A; u.ldb = NP;
-        u.C = K + (size_t)(r0 + NB) * NP + (r0 + NB); u.ldc = NP;
-        u.M = u.M_last = rem2; u.N = rem2; u.K = u.K_last = NB; u.nbatch = 1;
-        u.alpha = -1.0; u.beta = 1.0; u.lower_only = 1;
-        if (lookahead) {
-            const int slot = kb & 1;
-            hipEventRecord(ps.panel_done[slot], s);                 // panel(k) (and column part) issued before this point
-            hipStreamWaitEvent(ps.side, ps.panel_done[slot], 0);
-            launch_gemm<true>(ps.side, u);
-            hipEventRecord(ps.bulk_done[slot], ps.side);
-            bulk_pending = true; pending_slot = slot;
-        } else {
-            launch_gemm<true>(s, u);
-        }
-    }
-    if (bulk_pending) hipStreamWaitEvent(s, ps.bulk_done[pending_slot], 0);
-}
-
 // Two-level blocking: panels of OB = `ob_blocks` x NB columns are factored by k_potrf_step (one launch per NB
-// columns, left-looking inside the panel); the trailing matrix then gets ONE rank-OB update per panel (MFMA
-// GEMM on the block lower triangle), split as above into the next panel's columns (main stream) and the
-// rest (side stream, underneath the next panel's step launches).
+// columns, left-looking inside the panel); the trailing matrix then gets ONE rank-OB update per panel (MFMA GEMM on
+// the folded block lower triangle).  Everything runs in the caller's stream: running the update beside the next
+// panel's steps was tried twice (a second stream with events; update tiles riding in the step launches) and lost
+// both times — profiles/r01_fit_cholesky_ab.log.
 static int potrf_outer_blocks() {
     static int ob = 0;
     if (!ob) {
-        ob = 4;
+        ob = 2;
         if (const char* e = getenv("GPT_POTRF_OB")) { const int v = atoi(e) / NB; if (v >= 1 && v <= 8) ob = v; }
     }
     return ob;
 }
 
 void launch_potrf(hipStream_t s, double* K, double* W, int NP, int* info) {
-    static const bool legacy = getenv("GPT_POTRF_LEGACY") != nullptr;
-    if (legacy) { launch_potrf_legacy(s, K, W, NP, info); return; }
     const int nb = NP / NB;
     const int ob = potrf_outer_blocks();
     constexpr size_t step_lds = (size_t)(2 * NB * PS) * sizeof(double);
@@ -714,48 +609,21 @@ void launch_potrf(hipStream_t s, double* K, double* W, int NP, int* info) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_finish), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fin_lds);
         attr_set = true;
     }
-    PotrfStreams& ps = potrf_streams();
-    const bool lookahead = ps.ok && nb > 2 * ob;
-    bool bulk_pending = false;
-    int pending_slot = 0, slot = 0;
     for (int p0 = 0; p0 < nb; p0 += ob) {
         const int pend = p0 + ob < nb ? p0 + ob : nb;
         for (int kb = p0; kb < pend; ++kb)
-            hipLaunchKernelGGL(k_potrf_step, dim3(nb - kb), dim3(256), step_lds, s, K, W, NP, kb, p0, info);
+            hipLaunchKernelGGL(k_potrf_step, dim3(nb - kb), dim3(256), step_lds, s, K, W, NP, kb, p0, info GPT_TRACE_NULL);
         const int r0 = pend * NB, kw = (pend - p0) * NB;
         const int rem = NP - r0;
         if (rem <= 0) break;
-        // trailing update A22 -= L21 L21^T with the whole panel (K = kw): the next panel's columns first
-        if (bulk_pending) hipStreamWaitEvent(s, ps.bulk_done[pending_slot], 0);   // bulk(P-1) also wrote these columns
-        bulk_pending = false;
-        static const bool single_update = getenv("GPT_POTRF_LOOKAHEAD") == nullptr;
-        const int nw = single_update ? rem : (rem < ob * NB ? rem : ob * NB);
-        GemmArgs c{};
+        GemmArgs c{};                                   // trailing update A22 -= L21 L21^T with the whole panel (K = kw)
         c.A = K + (size_t)r0 * NP + (size_t)p0 * NB; c.lda = NP;
         c.B = c.A; c.ldb = NP;
         c.C = K + (size_t)r0 * NP + r0; c.ldc = NP;
-        c.M = c.M_last = rem; c.N = nw; c.K = c.K_last = kw; c.nbatch = 1;
+        c.M = c.M_last = rem; c.N = rem; c.K = c.K_last = kw; c.nbatch = 1;
         c.alpha = -1.0; c.beta = 1.0; c.lower_only = 1;
         launch_gemm<true>(s, c);
-        const int rem2 = rem - nw;
-        if (rem2 <= 0) continue;
-        GemmArgs u{};
-        u.A = K + (size_t)(r0 + nw) * NP + (size_t)p0 * NB; u.lda = NP;
-        u.B = u.A; u.ldb = NP;
-        u.C = K + (size_t)(r0 + nw) * NP + (r0 + nw); u.ldc = NP;
-        u.M = u.M_last = rem2; u.N = rem2; u.K = u.K_last = kw; u.nbatch = 1;
-        u.alpha = -1.0; u.beta = 1.0; u.lower_only = 1;
-        if (lookahead) {
-            hipEventRecord(ps.panel_done[slot], s);                 // panel P and the next panel's columns are done here
-            hipStreamWaitEvent(ps.side, ps.panel_done[slot], 0);
-            launch_gemm<true>(ps.side, u);
-            hipEventRecord(ps.bulk_done[slot], ps.side);
-            bulk_pending = true; pending_slot = slot; slot ^= 1;
-        } else {
-            launch_gemm<true>(s, u);
-        }
     }
-    if (bulk_pending) hipStreamWaitEvent(s, ps.bulk_done[pending_slot], 0);
     hipLaunchKernelGGL(k_potrf_finish, dim3(nb), dim3(256), fin_lds, s, K, W, NP);
 }
 
