@@ -58,10 +58,28 @@ def cpu_baseline(N, D, O, sample, jvar):
     t0 = time.perf_counter()
     orc.posterior_all_fast(Xq, X, L, a, c, ls, noise, want_jvar=jvar)
     t_pred = time.perf_counter() - t0
-    return {"value": sample / t_pred, "unit": "predictions/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"oracle.posterior_all_fast on {sample} of the queries at N={N} (mean+var+J"
-                      f"{'+Jvar' if jvar else ''}), numpy/scipy BLAS threads; CPU fit (Gram+potrf+potrs) took {t_fit:.1f} s",
-            "fit_s": t_fit}
+    out = {"value": sample / t_pred, "unit": "predictions/s", "cores": os.cpu_count(), "kind": "port",
+           "sample": f"oracle.posterior_all_fast on {sample} of the queries at N={N} (mean+var+J"
+                     f"{'+Jvar' if jvar else ''}), numpy/scipy BLAS threads; CPU fit (Gram+potrf+potrs) took {t_fit:.1f} s",
+           "fit_s": t_fit}
+    # The library the reference itself calls for fit / mean / std (gaussian_process.py:19-21, 37, 48): scikit-learn's
+    # GaussianProcessRegressor with the reference's kernel and optimizer=None, same inputs, mean + std only (the
+    # reference's Jacobian code is its own and does not exist on this box).  Reported beside the port, never as `value`.
+    try:
+        from sklearn.gaussian_process import GaussianProcessRegressor
+        from sklearn.gaussian_process.kernels import RBF, ConstantKernel, WhiteKernel
+        gpr = GaussianProcessRegressor(kernel=ConstantKernel(c) * RBF(ls) + WhiteKernel(noise), alpha=jit, optimizer=None)
+        t0 = time.perf_counter()
+        gpr.fit(X, Y)
+        t_sk_fit = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        gpr.predict(Xq, return_std=True)
+        t_sk = time.perf_counter() - t0
+        out["sklearn"] = {"fit_s": t_sk_fit, "mean_std_predictions_per_s": sample / t_sk,
+                          "what": f"GaussianProcessRegressor(optimizer=None).fit + predict(return_std=True) on {sample} queries"}
+    except ImportError:
+        out["sklearn"] = None
+    return out
 
 
 def main():

@@ -302,7 +302,7 @@ static int fit_impl(gpt_handle* h, const double* X, const double* Y, int64_t N, 
     launch_trinv(s, h->dK, h->dW, NP, h->dWf());
     HIPCHK(hipEventRecord(h->ev[3], s));
     for (int ps = 0; ps < l.npass; ++ps)
-        launch_alpha(s, h->dW, h->dY4 + (size_t)ps * NP * 4, (int)N, NP, h->dT4, h->dA4() + (size_t)ps * NP * 4);
+        launch_alpha(s, h->dW, h->dY4 + (size_t)ps * NP * 4, (int)N, NP, h->dT4, h->dA4() + (size_t)ps * NP * 4, h->dWf());
     HIPCHK(hipEventRecord(h->ev[4], s));
     launch_pack_w(s, h->dW, (int)N, NP, h->dWf());
     HIPCHK(hipEventRecord(h->ev[5], s));

@@ -42,7 +42,8 @@ void launch_gram(hipStream_t s, const double* Xs, int N, int NP, int ktype, doub
 void launch_add_lower(hipStream_t s, double* K, const double* S, int N, int NP);
 void launch_potrf(hipStream_t s, double* K, double* W, int NP, int* info);
 void launch_trinv(hipStream_t s, const double* L, double* W, int NP, double* scratch /* >= NP*NP/4 doubles */);
-void launch_alpha(hipStream_t s, const double* W, const double* Y4, int N, int NP, double* tmp4, double* A4);
+void launch_alpha(hipStream_t s, const double* W, const double* Y4, int N, int NP, double* tmp4, double* A4,
+                  double* scratch /* >= (NP/512)*NP*4 doubles */);
 void launch_pack_w(hipStream_t s, const double* W, int N, int NP, double* Wf);
 void launch_logdet(hipStream_t s, const double* K, int N, int NP, double* out);
 void launch_kinv(hipStream_t s, const double* W, int NP, double* Kout);

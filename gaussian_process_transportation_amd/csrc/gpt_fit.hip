@@ -664,8 +664,9 @@ void launch_trinv(hipStream_t s, const double* L, double* W, int NP, double* scr
 
 // =====================================================================================
 // alpha = K^-1 Y = W^T (W Y).   Y4 / tmp4 / A4 are [NP][4] (up to 4 outputs per pass).
-// fwd: one wave per row (coalesced row of W).  bwd: one workgroup per 64 columns, lanes on
-// columns (coalesced 512-B row segments), the 4 waves split the rows and reduce through LDS.
+// fwd: one wave per row (coalesced row of W).  bwd: workgroups on 64-column x 512-row pieces, lanes on columns
+// (coalesced 512-B row segments), the 4 waves split the rows and reduce through LDS; `scratch` holds the
+// (NP/512) x NP x 4 partial sums.
 // =====================================================================================
 __global__ __launch_bounds__(256) void k_alpha_fwd(const double* __restrict__ W, const double* __restrict__ Y4, int NP,
                                                    double* __restrict__ T4) {
@@ -686,14 +687,21 @@ __global__ __launch_bounds__(256) void k_alpha_fwd(const double* __restrict__ W,
     if (lane == 0) *reinterpret_cast<d4*>(T4 + (size_t)i * 4) = d4{s0, s1, s2, s3};
 }
 
-__global__ __launch_bounds__(256) void k_alpha_bwd(const double* __restrict__ W, const double* __restrict__ T4, int N, int NP,
-                                                   double* __restrict__ A4) {
+// bwd, first pass: workgroup (strip, chunk) sums rows [chunk*ALPHA_ROWS, +ALPHA_ROWS) of a 64-column strip into
+// part[chunk][j][4]; second pass adds the chunks in order (deterministic; no atomics).
+constexpr int ALPHA_ROWS = 512;
+
+__global__ __launch_bounds__(256) void k_alpha_bwd(const double* __restrict__ W, const double* __restrict__ T4, int NP,
+                                                   double* __restrict__ part) {
     __shared__ double red[4][64][4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int j0 = blockIdx.x * 64;
+    const int j0 = blockIdx.x * 64, i0 = blockIdx.y * ALPHA_ROWS;
+    if (i0 + ALPHA_ROWS <= j0) return;                  // strictly above the diagonal: zeros (never read back either)
     const int j = j0 + lane;
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    for (int i = j0 + w; i < NP; i += 4) {
+    const int ibeg = (i0 > j0 ? i0 : j0) + w;
+#pragma unroll 4
+    for (int i = ibeg; i < i0 + ALPHA_ROWS; i += 4) {
         const double wv = W[(size_t)i * NP + j];        // zero above the diagonal
         const d4 tv = *reinterpret_cast<const d4*>(T4 + (size_t)i * 4);
         s0 += wv * tv[0]; s1 += wv * tv[1]; s2 += wv * tv[2]; s3 += wv * tv[3];
@@ -704,14 +712,23 @@ __global__ __launch_bounds__(256) void k_alpha_bwd(const double* __restrict__ W,
         d4 r;
 #pragma unroll
         for (int o = 0; o < 4; ++o) r[o] = red[0][lane][o] + red[1][lane][o] + red[2][lane][o] + red[3][lane][o];
-        if (j >= N) r = d4{0, 0, 0, 0};
-        *reinterpret_cast<d4*>(A4 + (size_t)j * 4) = r;
+        *reinterpret_cast<d4*>(part + ((size_t)blockIdx.y * NP + j) * 4) = r;
     }
 }
 
-void launch_alpha(hipStream_t s, const double* W, const double* Y4, int N, int NP, double* tmp4, double* A4) {
+__global__ __launch_bounds__(256) void k_alpha_sum(const double* __restrict__ part, int N, int NP, double* __restrict__ A4) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= NP) return;
+    d4 r{0, 0, 0, 0};
+    for (int ch = j / ALPHA_ROWS; ch < NP / ALPHA_ROWS; ++ch) r += *reinterpret_cast<const d4*>(part + ((size_t)ch * NP + j) * 4);
+    if (j >= N) r = d4{0, 0, 0, 0};
+    *reinterpret_cast<d4*>(A4 + (size_t)j * 4) = r;
+}
+
+void launch_alpha(hipStream_t s, const double* W, const double* Y4, int N, int NP, double* tmp4, double* A4, double* scratch) {
     hipLaunchKernelGGL(k_alpha_fwd, dim3(NP / 4), dim3(256), 0, s, W, Y4, NP, tmp4);
-    hipLaunchKernelGGL(k_alpha_bwd, dim3(NP / 64), dim3(256), 0, s, W, tmp4, N, NP, A4);
+    hipLaunchKernelGGL(k_alpha_bwd, dim3(NP / 64, NP / ALPHA_ROWS), dim3(256), 0, s, W, tmp4, NP, scratch);
+    hipLaunchKernelGGL(k_alpha_sum, dim3((NP + 255) / 256), dim3(256), 0, s, scratch, N, NP, A4);
 }
 
 // =====================================================================================
