@@ -26,7 +26,11 @@ for N in Ns:
         if best is None or t["total"] < best[0]["total"]:
             best = (t, wall)
     t, wall = best
-    msg = f"[{tag}] N={N}: " + "  ".join(f"{k} {v:.2f}" for k, v in t.items()) + f"  (host wall {wall:.1f} ms)"
+    t0 = time.perf_counter()
+    for _ in range(3):
+        h.lml_gradient(3)
+    t_grad = (time.perf_counter() - t0) / 3 * 1e3
+    msg = f"[{tag}] N={N}: " + "  ".join(f"{k} {v:.2f}" for k, v in t.items()) + f"  (host wall {wall:.1f} ms; lml_gradient {t_grad:.2f} ms)"
     if N <= 2500:      # factor against LAPACK
         d = X[:, None, :] - X[None, :, :]
         Kref = 0.1 * np.exp(-0.5 * (d * d).sum(-1) / 0.01) + (1e-4 + 1e-10) * np.eye(N)
