@@ -26,10 +26,13 @@ for N in Ns:
         if best is None or t["total"] < best[0]["total"]:
             best = (t, wall)
     t, wall = best
-    t0 = time.perf_counter()
+    t_grad = 1e9                       # one optimizer evaluation = fit + lml_gradient (which consumes the factor)
     for _ in range(3):
+        h.fit(X, Y, ls, 0.1, 1e-4, 1e-10)
+        t0 = time.perf_counter()
         h.lml_gradient(3)
-    t_grad = (time.perf_counter() - t0) / 3 * 1e3
+        t_grad = min(t_grad, (time.perf_counter() - t0) * 1e3)
+    h.fit(X, Y, ls, 0.1, 1e-4, 1e-10)
     msg = f"[{tag}] N={N}: " + "  ".join(f"{k} {v:.2f}" for k, v in t.items()) + f"  (host wall {wall:.1f} ms; lml_gradient {t_grad:.2f} ms)"
     if N <= 2500:      # factor against LAPACK
         d = X[:, None, :] - X[None, :, :]
