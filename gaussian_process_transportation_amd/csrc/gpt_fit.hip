@@ -373,14 +373,19 @@ __global__ __launch_bounds__(256) void k_potrf_finish(double* __restrict__ K, do
 }
 
 // =====================================================================================
-// Generic fp64 MFMA GEMM, 128x128 output tile per workgroup (4 waves, 2x2, 64x64 each),
-// K consumed in LDS-staged chunks of 32:  C = alpha * A * op(B) + beta * C.
+// Generic fp64 MFMA GEMM:  C = alpha * A * op(B) + beta * C,  one TS x TS output tile per workgroup
+// (TS = 128 or 64; 4 waves as 2 x 2, (TS/2)^2 each), K consumed in LDS-staged chunks of 32.
 //   BT = true : op(B) = B^T, B stored [n][k] row-major (SYRK / TRSM-by-inverse)
 //   BT = false: op(B) = B,   B stored [k][n] row-major (triangular-inverse products)
+//   AT = true : A is given transposed, A(i,k) = Amem[k*lda + i] (K^-1 = W^T W)
 // All dims are multiples of 64; partial 128-tiles are guarded per 64x64 wave quadrant.
-// LDS strides: [row][k] images use 34 doubles per row, [k][n] images 144 — both make the
+// LDS strides: [row][k] images use 34 doubles per row, [k][n] images TS + 16 — both make the
 // 16x4 fragment reads (ds_read_b64, two 32-lane halves) bank-conflict free.
-// Batched over blockIdx.z with element strides; the last batch may have its own M / K.
+// Batched with element strides; the last batch entry may have its own M / K.
+// TS = 64 is for problems with few tiles: a tile's K loop is a serial chain (a 128-tile with K = 2048 lives
+// 0.5 ms however idle the chip is), so when there are not enough 128-tiles to fill 2 x 256 workgroup slots the
+// quarter-size tiles cut that chain by four and fill the chip (the lower levels of the triangular inverse, the late
+// trailing updates of the Cholesky, everything at N <= 4096).
 // =====================================================================================
 struct GemmArgs {
     const double* A; long lda; long sA;
@@ -391,13 +396,12 @@ struct GemmArgs {
     int nbatch;
     double alpha, beta;
     int lower_only;          // skip tiles strictly above the block diagonal (SYRK)
-    int a_lower;             // A lower triangular: k < i0 + 128
+    int a_lower;             // A lower triangular: k < i0 + TS
     int b_lower;             // B lower triangular (BT=false): k >= j0
     int k_from_ij;           // both operands vanish for k < max(i0, j0) (W^T W with W lower triangular)
 };
 
 constexpr int GA_S = 34;     // [row][k] stride
-constexpr int GB_S = 144;    // [k][n] stride
 
 // Tile -> workgroup mapping.  Workgroups are dealt round-robin over the 8 XCDs (linear id mod 8) and each XCD has
 // its own L2, so the 1-D grid is decoded as (xcd = id % 8, s = id / 8).  Tile rows of all batch entries are
@@ -406,11 +410,14 @@ constexpr int GB_S = 144;    // [k][n] stride
 // starts the longest tiles first (greedy longest-processing-time: the K range of a tile shrinks with tj when B is
 // triangular, grows with ti when A is, shrinks with ti for W^T W), and the ~64 workgroups it runs at a time share
 // a few row and column panels in that XCD's L2.
-// AT = true: A is given transposed, A(i,k) = Amem[k*lda + i] (used for K^-1 = W^T W).
-template <bool BT, bool AT = false>
+template <bool BT, bool AT, int TS>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int TM, int TN, int G, int fold_tm, const int vid, double* smem) {
-    double* As = smem;                                       // [128][GA_S]   (AT: [32][GB_S])
-    double* Bs = smem + (AT ? 32 * GB_S : 128 * GA_S);       // BT: [128][GA_S]   else: [32][GB_S]
+    constexpr int WS = TS / 2;              // wave tile edge
+    constexpr int RT = WS / 16;             // MFMA tiles per wave tile edge
+    constexpr int GB_S = TS + 16;           // [k][n] stride
+    constexpr int NP_ = TS / 16;            // staging passes per operand and chunk (one 16-byte load per thread each)
+    double* As = smem;                                       // [TS][GA_S]   (AT: [32][GB_S])
+    double* Bs = smem + (AT ? 32 * GB_S : TS * GA_S);        // BT: [TS][GA_S]   else: [32][GB_S]
     int b, ti, tj;
     {
         const int xcd = vid & 7, sidx = vid >> 3;
@@ -438,80 +445,81 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int TM, int TN, int
     const int M = last ? g.M_last : g.M;
     const int K = last ? g.K_last : g.K;
     const int N = g.N;
-    const int i0 = ti * 128, j0 = tj * 128;
+    const int i0 = ti * TS, j0 = tj * TS;
     if (i0 >= M || j0 >= N) return;
     if (g.lower_only && j0 > i0) return;
     const double* A = g.A + (size_t)b * g.sA;
     const double* B = g.B + (size_t)b * g.sB;
     double* C = g.C + (size_t)b * g.sC;
     int kbeg = 0, kend = K;
-    if (g.a_lower) kend = min(K, i0 + 128);
+    if (g.a_lower) kend = min(K, i0 + TS);
     if (g.b_lower) kbeg = j0;
     if (g.k_from_ij) kbeg = i0 > j0 ? i0 : j0;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int wr = w >> 1, wc = w & 1;
     const int lc = lane & 15, lk = lane >> 4;
-    const bool active = (i0 + 64 * wr < M) && (j0 + 64 * wc < N) && !(g.lower_only && i0 == j0 && wc > wr);
+    const bool active = (i0 + WS * wr < M) && (j0 + WS * wc < N) && !(g.lower_only && i0 == j0 && wc > wr);
     // beta != 0: the accumulators start from (beta/alpha) C, so the read of C flies under the first chunk's
     // staging instead of sitting in the epilogue (the rank-k updates of the Cholesky have only 4-8 chunks per tile)
-    d4 acc[4][4];
+    d4 acc[RT][RT];
     const double cscale = g.beta != 0.0 ? g.beta / g.alpha : 0.0;
-    double* const ctile = C + (size_t)(i0 + 64 * wr + lk) * g.ldc + j0 + 64 * wc + lc;     // this lane's first element
-    if (active && cscale != 0.0) {          // one uniform branch, then 64 independent loads in flight together
+    double* const ctile = C + (size_t)(i0 + WS * wr + lk) * g.ldc + j0 + WS * wc + lc;     // this lane's first element
+    if (active && cscale != 0.0) {          // one uniform branch, then all the loads in flight together
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < RT; ++r)
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
+            for (int c = 0; c < RT; ++c)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[r][c][e] = ctile[(size_t)(16 * r + 4 * e) * g.ldc + 16 * c];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < RT; ++r)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[r][c] *= cscale;
+            for (int c = 0; c < RT; ++c) acc[r][c] *= cscale;
     } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < RT; ++r)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[r][c] = d4{0, 0, 0, 0};
+            for (int c = 0; c < RT; ++c) acc[r][c] = d4{0, 0, 0, 0};
     }
 
     // global -> registers one chunk ahead of the MFMAs (the loads of chunk k+1 fly under the MFMAs of chunk k),
     // registers -> LDS between two barriers.  Every wave-level load covers whole 128-B lines:
-    //   [row][k] sources (A, and B when BT): 16 lanes x 16 B along k, 4 rows per instruction, 8 instructions;
-    //   [k][n] sources (B when !BT, A when AT): 64 lanes x 16 B along n/i, one k row per instruction.
-    const int rk_r = t >> 4, rk_k = (t & 15) * 2;        // [row][k] staging: row rk_r + 16u, k offset rk_k
-    const int kn_k = t >> 6, kn_n = (t & 63) * 2;        // [k][n]  staging: k row kn_k + 4u, n offset kn_n
+    //   [row][k] sources (A, and B when BT): 16 lanes x 16 B along k, 4 rows per instruction;
+    //   [k][n] sources (B when !BT, A when AT): TS/2 lanes x 16 B along n/i per k row.
+    const int rk_r = t >> 4, rk_k = (t & 15) * 2;                 // [row][k] staging: row rk_r + 16u, k offset rk_k
+    constexpr int KN_L = TS / 2, KN_R = 256 / KN_L;               // [k][n] staging: lanes per k row, k rows per pass
+    const int kn_k = t / KN_L, kn_n = (t % KN_L) * 2;             //                  k row kn_k + KN_R u, n offset kn_n
     // uniform (scalar) base per instruction + one per-lane 32-bit offset per operand keeps the address registers few
     const int offA = AT ? kn_k * (int)g.lda + kn_n : rk_r * (int)g.lda + rk_k;
     const int offB = BT ? rk_r * (int)g.ldb + rk_k : kn_k * (int)g.ldb + kn_n;
     const bool okA_n = (i0 + kn_n) < M, okB_n = (j0 + kn_n) < N;     // all dims are multiples of 64
-    d2 pa[8], pb[8];
+    d2 pa[NP_], pb[NP_];
     auto fetch = [&](int kc) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < NP_; ++u) {
             if (!AT) {
                 const double* base = A + (size_t)(i0 + 16 * u) * g.lda + kc;
                 pa[u] = (i0 + 16 * u) < M ? *reinterpret_cast<const d2*>(base + offA) : d2{0, 0};
             } else {
-                const double* base = A + (size_t)(kc + 4 * u) * g.lda + i0;
+                const double* base = A + (size_t)(kc + KN_R * u) * g.lda + i0;
                 pa[u] = okA_n ? *reinterpret_cast<const d2*>(base + offA) : d2{0, 0};
             }
             if (BT) {
                 const double* base = B + (size_t)(j0 + 16 * u) * g.ldb + kc;
                 pb[u] = (j0 + 16 * u) < N ? *reinterpret_cast<const d2*>(base + offB) : d2{0, 0};
             } else {
-                const double* base = B + (size_t)(kc + 4 * u) * g.ldb + j0;
+                const double* base = B + (size_t)(kc + KN_R * u) * g.ldb + j0;
                 pb[u] = okB_n ? *reinterpret_cast<const d2*>(base + offB) : d2{0, 0};
             }
         }
     };
     auto stage = [&]() {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < NP_; ++u) {
             if (!AT) *reinterpret_cast<d2*>(&As[(rk_r + 16 * u) * GA_S + rk_k]) = pa[u];
-            else     *reinterpret_cast<d2*>(&As[(kn_k + 4 * u) * GB_S + kn_n]) = pa[u];
+            else     *reinterpret_cast<d2*>(&As[(kn_k + KN_R * u) * GB_S + kn_n]) = pa[u];
             if (BT)  *reinterpret_cast<d2*>(&Bs[(rk_r + 16 * u) * GA_S + rk_k]) = pb[u];
-            else     *reinterpret_cast<d2*>(&Bs[(kn_k + 4 * u) * GB_S + kn_n]) = pb[u];
+            else     *reinterpret_cast<d2*>(&Bs[(kn_k + KN_R * u) * GB_S + kn_n]) = pb[u];
         }
     };
     if (kbeg < kend) fetch(kbeg);
@@ -522,19 +530,19 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int TM, int TN, int
         if (active) {
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
-                double a[4], bb[4];
+                double a[RT], bb[RT];
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    a[r] = AT ? As[(4 * s + lk) * GB_S + 64 * wr + 16 * r + lc]
-                              : As[(64 * wr + 16 * r + lc) * GA_S + 4 * s + lk];
+                for (int r = 0; r < RT; ++r)
+                    a[r] = AT ? As[(4 * s + lk) * GB_S + WS * wr + 16 * r + lc]
+                              : As[(WS * wr + 16 * r + lc) * GA_S + 4 * s + lk];
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    bb[c] = BT ? Bs[(64 * wc + 16 * c + lc) * GA_S + 4 * s + lk]
-                               : Bs[(4 * s + lk) * GB_S + 64 * wc + 16 * c + lc];
+                for (int c = 0; c < RT; ++c)
+                    bb[c] = BT ? Bs[(WS * wc + 16 * c + lc) * GA_S + 4 * s + lk]
+                               : Bs[(4 * s + lk) * GB_S + WS * wc + 16 * c + lc];
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+                for (int r = 0; r < RT; ++r)
 #pragma unroll
-                    for (int c = 0; c < 4; ++c)
+                    for (int c = 0; c < RT; ++c)
                         acc[r][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r], bb[c], acc[r][c], 0, 0, 0);
             }
         }
@@ -543,42 +551,56 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int TM, int TN, int
     if (!active) return;
     const double alpha = g.alpha;
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < RT; ++r)
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+        for (int c = 0; c < RT; ++c)
 #pragma unroll
             for (int e = 0; e < 4; ++e) ctile[(size_t)(16 * r + 4 * e) * g.ldc + 16 * c] = alpha * acc[r][c][e];
 }
 
-template <bool BT, bool AT = false>
+template <bool BT, bool AT, int TS>
 __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g, int TM, int TN, int G, int fold_tm) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    gemm_tile<BT, AT>(g, TM, TN, G, fold_tm, blockIdx.x, smem);
+    gemm_tile<BT, AT, TS>(g, TM, TN, G, fold_tm, blockIdx.x, smem);
 }
 
 struct GemmGrid { int TM, TN, G, fold_tm, nvid; };
-static GemmGrid gemm_grid(const GemmArgs& g) {
+static GemmGrid gemm_grid(const GemmArgs& g, int TS) {
     GemmGrid q{};
     const int Mmax = g.M > g.M_last ? g.M : g.M_last;
-    q.TM = (Mmax + 127) / 128; q.TN = (g.N + 127) / 128;
+    q.TM = (Mmax + TS - 1) / TS; q.TN = (g.N + TS - 1) / TS;
     if (g.lower_only && g.nbatch == 1 && q.TM == q.TN && q.TM > 1) { q.fold_tm = q.TM; q.TM = (q.fold_tm + 1) / 2; q.TN = q.fold_tm + 1; }
     q.G = (g.nbatch * q.TM + 7) / 8;            // tile rows (over all batch entries) per XCD
     q.nvid = 8 * q.G * q.TN;
     return q;
 }
 
-template <bool BT, bool AT = false>
-static void launch_gemm(hipStream_t s, const GemmArgs& g) {
-    const GemmGrid q = gemm_grid(g);
-    const int TM = q.TM, TN = q.TN, G = q.G, fold_tm = q.fold_tm;
-    dim3 grid(q.nvid);
-    constexpr size_t lds = (size_t)((AT ? 32 * GB_S : 128 * GA_S) + (BT ? 128 * GA_S : 32 * GB_S)) * sizeof(double);
+template <bool BT, bool AT, int TS>
+static void launch_gemm_ts(hipStream_t s, const GemmArgs& g) {
+    const GemmGrid q = gemm_grid(g, TS);
+    constexpr size_t lds = (size_t)((AT ? 32 * (TS + 16) : TS * GA_S) + (BT ? TS * GA_S : 32 * (TS + 16))) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<BT, AT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<BT, AT, TS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_gemm<BT, AT>), grid, dim3(256), lds, s, g, TM, TN, G, fold_tm);
+    hipLaunchKernelGGL((k_gemm<BT, AT, TS>), dim3(q.nvid), dim3(256), lds, s, g, q.TM, q.TN, q.G, q.fold_tm);
+}
+
+// 64-tiles below this many 128-tiles (measured: equal within noise from 2500 up, tools/gpu_fit_ab.sh; a 4096^3 product runs at 64.6 vs 66.3 TFLOP/s)
+static int gemm_tile_threshold() {
+    static int thr = -1;
+    if (thr < 0) { thr = 2500; if (const char* e = getenv("GPT_GEMM_TS64_BELOW")) thr = atoi(e); }
+    return thr;
+}
+
+template <bool BT, bool AT = false>
+static void launch_gemm(hipStream_t s, const GemmArgs& g) {
+    const int Mmax = g.M > g.M_last ? g.M : g.M_last;
+    double tiles = (double)g.nbatch * ((Mmax + 127) / 128) * ((g.N + 127) / 128);
+    if (g.lower_only) tiles *= 0.5;
+    if (tiles < gemm_tile_threshold()) launch_gemm_ts<BT, AT, 64>(s, g);
+    else launch_gemm_ts<BT, AT, 128>(s, g);
 }
 
 // =====================================================================================

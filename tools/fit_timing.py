@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gaussian_process_transportation_amd import _lib  # noqa: E402
 
 Ns = [int(a) for a in sys.argv[1:]] or [1024, 2500, 8192]
-tag = "legacy" if os.environ.get("GPT_POTRF_LEGACY") else "OB=" + os.environ.get("GPT_POTRF_OB", "256")
+tag = " ".join(f"{k[4:]}={v}" for k, v in sorted(os.environ.items()) if k.startswith("GPT_")) or "defaults"
 for N in Ns:
     rng = np.random.default_rng(0)
     X = rng.uniform(0, 1, (N, 3))

@@ -5,7 +5,7 @@
 #include <cstdio>
 #include <vector>
 using namespace gpt;
-template <bool BT>
+template <bool BT, int TS = 128>
 static double run(int n, long ld, int reps) {
     double *A, *B, *C;
     size_t bytes = (size_t)n * ld * sizeof(double);
@@ -15,10 +15,10 @@ static double run(int n, long ld, int reps) {
     g.A = A; g.lda = ld; g.B = B; g.ldb = ld; g.C = C; g.ldc = ld;
     g.M = g.M_last = n; g.N = n; g.K = g.K_last = n; g.nbatch = 1; g.alpha = 1.0; g.beta = 0.0;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    launch_gemm<BT>(0, g);
+    launch_gemm_ts<BT, false, TS>(0, g);
     hipDeviceSynchronize();
     hipEventRecord(e0, 0);
-    for (int r = 0; r < reps; ++r) launch_gemm<BT>(0, g);
+    for (int r = 0; r < reps; ++r) launch_gemm_ts<BT, false, TS>(0, g);
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     hipFree(A); hipFree(B); hipFree(C);
@@ -53,15 +53,19 @@ static void syrk(int rem, int kw, long ld, double beta, int lower, bool same_ab,
 int main() {
     for (long pad : {0L, 32L})
         printf("n=4096 ld=8192+%ld: BT=false %.1f TF   BT=true %.1f TF\n", pad, run<false>(4096, 8192 + pad, 5), run<true>(4096, 8192 + pad, 5));
+    printf("n=2048: 128-tiles BT=false %.1f TF  BT=true %.1f TF | 64-tiles BT=false %.1f TF  BT=true %.1f TF\n", run<false>(2048, 8192, 20),
+           run<true>(2048, 8192, 20), run<false, 64>(2048, 8192, 20), run<true, 64>(2048, 8192, 20));
+    printf("n=1024: 128-tiles BT=false %.1f TF  BT=true %.1f TF | 64-tiles BT=false %.1f TF  BT=true %.1f TF\n", run<false>(1024, 8192, 50),
+           run<true>(1024, 8192, 50), run<false, 64>(1024, 8192, 50), run<true, 64>(1024, 8192, 50));
+    printf("n=4096: 64-tiles BT=false %.1f TF  BT=true %.1f TF\n", run<false, 64>(4096, 8192, 5), run<true, 64>(4096, 8192, 5));
+    // rank-K trailing updates through launch_gemm's own choice of tile (env GPT_GEMM_TS64_BELOW)
     syrk(7680, 256, 8192, 1.0, 1, true, 10);
-    syrk(7680, 256, 8192, 0.0, 1, true, 10);
-    syrk(7680, 256, 8192, 1.0, 0, true, 10);
     syrk(7680, 256, 8192, 0.0, 0, true, 10);
-    syrk(7680, 256, 8192, 0.0, 0, false, 10);
-    syrk(7680, 256, 8192 + 32, 1.0, 1, true, 10);
-    syrk(7680, 512, 8192, 1.0, 1, true, 10);
-    syrk(7680, 1024, 8192, 1.0, 1, true, 10);
+    syrk(7680, 128, 8192, 1.0, 1, true, 10);
     syrk(4096, 256, 8192, 1.0, 1, true, 10);
+    syrk(4096, 128, 8192, 1.0, 1, true, 10);
     syrk(2048, 256, 8192, 1.0, 1, true, 10);
+    syrk(2048, 128, 8192, 1.0, 1, true, 10);
+    syrk(1024, 128, 8192, 1.0, 1, true, 10);
     return 0;
 }
