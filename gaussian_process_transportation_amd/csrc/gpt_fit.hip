@@ -105,13 +105,6 @@ __device__ __forceinline__ double quad_bcast(double v) {
     return __hiloint2double(hi, lo);
 }
 
-// value of lane `src` (wave-uniform index) as a scalar
-__device__ __forceinline__ double lane_value(double v, int src) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
-    return __hiloint2double(hi, lo);
-}
-
 #ifdef GPT_STEP_TRACE      // tools/probes/potrf_step_probe.hip: shader-clock stamps of workgroup 1's phases
 #define GPT_TRACE_ARG , long long* trace
 #define GPT_TRACE_NULL , nullptr
@@ -121,10 +114,12 @@ __device__ __forceinline__ double lane_value(double v, int src) {
 #define GPT_TRACE_NULL
 #define GPT_TRACE(i) do { } while (0)
 #endif
-__device__ __forceinline__ void potrf_step_body(double* __restrict__ K, double* __restrict__ W, int NP, int kb, int p0,
-                                                int* __restrict__ info, const int b, double* smem GPT_TRACE_ARG) {
+__global__ __launch_bounds__(256) void k_potrf_step(double* __restrict__ K, double* __restrict__ W, int NP, int kb, int p0,
+                                                    int* __restrict__ info GPT_TRACE_ARG) {
     __shared__ __attribute__((aligned(16))) double colp[2][NB];
     __shared__ double dinv[NB];
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int b = blockIdx.x;
     GPT_TRACE(0);
     double* Ab = smem;               // L[r,j] image [NB][PS]; later the block B / X, stride DS
     double* Bb = smem + NB * PS;     // L[kb,j] image [NB][PS]; later D, then L11, stride DS
@@ -313,16 +308,6 @@ __device__ __forceinline__ void potrf_step_body(double* __restrict__ K, double* 
 #pragma unroll
     for (int m = 0; m < 16; ++m) K[(r0 + row) * NP + k0 + q + 4 * m] = x[m];
     GPT_TRACE(5);
-}
-
-__global__ __launch_bounds__(256) void k_potrf_step(double* __restrict__ K, double* __restrict__ W, int NP, int kb, int p0,
-                                                    int* __restrict__ info GPT_TRACE_ARG) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-#ifdef GPT_STEP_TRACE
-    potrf_step_body(K, W, NP, kb, p0, info, blockIdx.x, smem, trace);
-#else
-    potrf_step_body(K, W, NP, kb, p0, info, blockIdx.x, smem);
-#endif
 }
 
 // After the last step: for every diagonal block, move the parked L11 from W into K (zeros above the diagonal)
