@@ -106,9 +106,15 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # GPT_BENCH_FORCE_DIST=1 runs the multi-rank code path (RCCL init, model broadcast, barriers, max-reduce) with
+    # however many ranks there are, also one: the rehearsal available on a one-GPU box
+    use_dist = world > 1 or os.environ.get("GPT_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     N, D, O, M = args.n_source, 3, 3, args.queries
@@ -127,7 +133,7 @@ def main():
         fit_ms = (time.perf_counter() - t0) * 1e3
         fit_timings = h.fit_timings()
     bcast_bytes = 0
-    if world > 1:
+    if use_dist:
         dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -149,7 +155,7 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -166,7 +172,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     h.set_profiling(False)
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -213,7 +219,7 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
     h.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
