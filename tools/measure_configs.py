@@ -42,3 +42,30 @@ if __name__ == "__main__":
     tp = best(lambda: h.predict_all(Xq, mean=True, var=True, J=True, Jvar=True), reps=2)
     print(f"cfg3 + Jacobian variance through host buffers: {tp[1]*1e3:.1f} ms = {500_000/tp[1]:.0f} q/s")
     h.close()
+
+    # configs[4]: SVGP exact-conversion predictor, Z = 2048 inducing points, T = D = 3 tasks, synthetic SPD pseudo-point
+    # covariances, here in fp64 (the reference computes it in fp32); M = 1e6 in 4 slices of 250k
+    from gaussian_process_transportation_amd.svgp_exact import SVGPExactPredictor
+    Z, T, M = 2048, 3, 1_000_000
+    rng = np.random.default_rng(0)
+    xz = rng.uniform(0, 1, (Z, 3))
+    S = np.empty((T, Z, Z))
+    for t in range(T):
+        A = rng.standard_normal((Z, Z))
+        S[t] = A @ A.T / Z + 1e-3 * np.eye(Z)
+    yz = rng.standard_normal((T, Z))
+    t0 = time.perf_counter()
+    pred = SVGPExactPredictor(xz, S, yz, np.ones(T), np.array([0.2, 0.2, 0.2]))
+    t_conv = time.perf_counter() - t0
+    xq = np.random.default_rng(1).uniform(0, 1, (M, 3))
+    pred.posterior_f(xq[:1000], return_std=True); pred.posterior_f_prime(xq[:1000], return_std=True)
+    t0 = time.perf_counter()
+    for a in range(0, M, 250_000):
+        pred.posterior_f(xq[a:a + 250_000], return_std=True)
+    t_f = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for a in range(0, M, 250_000):
+        pred.posterior_f_prime(xq[a:a + 250_000], return_std=True)
+    t_fp = time.perf_counter() - t0
+    print(f"cfg5 SVGP exact conversion Z={Z} T={T} M={M} (fp64, host buffers): convert {t_conv*1e3:.0f} ms, posterior_f mean+std "
+          f"{t_f*1e3:.0f} ms = {M/t_f:.0f} q/s, posterior_f_prime J+J_std {t_fp*1e3:.0f} ms = {M/t_fp:.0f} q/s")
