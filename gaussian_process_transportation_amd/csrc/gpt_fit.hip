@@ -117,7 +117,7 @@ __device__ __forceinline__ double quad_bcast(double v) {
 __global__ __launch_bounds__(256) void k_potrf_step(double* __restrict__ K, double* __restrict__ W, int NP, int kb, int p0,
                                                     int* __restrict__ info GPT_TRACE_ARG) {
     __shared__ __attribute__((aligned(16))) double colp[2][NB];
-    __shared__ double dinv[NB];
+    __shared__ double dinv[NB], diagp[2], spare[64];
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int b = blockIdx.x;
     GPT_TRACE(0);
@@ -204,24 +204,50 @@ __global__ __launch_bounds__(256) void k_potrf_step(double* __restrict__ K, doub
 
     // ---- factor D: lane = row, wave w keeps the row's columns w + 4m in registers:  a[row][c] -= a[row][j] a[c][j] / a[j][j].
     // Column j is published through LDS in wave-major order (colp[(c&3)*16 + (c>>2)] = a[c][j]), so that after the
-    // barrier every wave fetches the multipliers of ITS columns with wave-uniform 16-byte reads, its own row's entry
-    // with one more, and the pivot with a uniform read — no cross-lane traffic.  The element of column j+1 is updated
-    // and published first; the other updates of step j run while that write is on its way to the barrier.
+    // barrier every wave fetches the multipliers of ITS columns with wave-uniform 16-byte reads and its own row's entry
+    // with one more — no cross-lane traffic.  What the next barrier waits for is kept short:
+    //   * the element of column j+1 is updated and published first, the other updates of step j run behind it;
+    //   * the pivot's reciprocal is not on that path: next to column j its wave publishes the not-yet-updated diagonal
+    //     entry a[j+1][j+1], every thread forms pivot j+1 = a[j+1][j+1] - a[j+1][j]^2 / a[j][j] itself — the very fma
+    //     lane j+1 executes, so bit-identical to the entry that gets published — and takes 1/pivot (v_rcp_f64 + two
+    //     Newton steps, <= 2 ulp) while the updates run.
     double a[16];
 #pragma unroll
     for (int m = 0; m < 16; ++m) a[m] = Bb[lane * DS + w + 4 * m];
     double dreg = 1.0;               // lane j ends up with pivot j
     const int self = (lane & 3) * 16 + (lane >> 2);
-    bool bad_seen = false;
+    int first_bad = 0;               // 1-based column of the first pivot <= 0 (or NaN); uniform over the workgroup and the grid
+    auto checked_pivot = [&](const double d, const int j) {     // branch-free: a failed pivot is replaced by 1
+        const bool ok = d > 0.0;
+        first_bad = (first_bad == 0 && !ok) ? j + 1 : first_bad;
+        return ok ? d : 1.0;
+    };
+    auto reciprocal = [](const double d) {
+        double r = __builtin_amdgcn_rcp(d);
+        r = fma(fma(-d, r, 1.0), r, r);
+        return fma(fma(-d, r, 1.0), r, r);
+    };
+    // the publishing stores are unconditional: waves that do not own the column write to a spare slot instead of branching
+    double* const pub_col[2] = {colp[0] + self, colp[1] + self};
+    double* const pub_none = spare + (t & 63);
     if (w == 0) colp[0][self] = a[0];
+    if (w == 1 && lane == 1) diagp[0] = a[0];             // a[1][1]
+    __syncthreads();
+    double rinv;                                           // 1 / pivot j at the top of step j
+    {
+        const double d0 = checked_pivot(colp[0][0], 0);
+        if (lane == 0) dreg = d0;
+        rinv = reciprocal(d0);
+    }
     auto factor_column = [&](auto jc) {
         constexpr int j = decltype(jc)::value;
         constexpr int ow = j & 3, om = j >> 2;
         constexpr int nw = (j + 1) & 3, nm = (j + 1) >> 2;    // owner wave / register of column j+1
-        __syncthreads();
+        constexpr int pw = (j + 2) & 3, pm = (j + 2) >> 2;    // ... of column j+2 (its diagonal entry goes out one step early)
+        constexpr bool has_n = j + 1 < NB, has_p = j + 2 < NB;
+        if constexpr (j > 0) __syncthreads();
         const double* col = colp[j & 1];
-        const double cr = col[self];
-        double d = col[ow * 16 + om];
+        double cr = col[self];
         double sc[16];
 #pragma unroll
         for (int m = 0; m < 16; m += 2)
@@ -229,37 +255,38 @@ __global__ __launch_bounds__(256) void k_potrf_step(double* __restrict__ K, doub
                 const d2 v = *reinterpret_cast<const d2*>(&col[w * 16 + m]);
                 sc[m] = v[0]; sc[m + 1] = v[1];
             }
-        if (!(d > 0.0)) {            // also catches NaN; uniform over the workgroup (and over the grid)
-            if (b == 0 && t == 0 && !bad_seen) atomicCAS(info, 0, (int)k0 + j + 1);
-            bad_seen = true;
-            d = 1.0;
-        }
-        if (lane == j) dreg = d;
-        // 1/d by v_rcp_f64 + two Newton steps (<= 2 ulp) instead of the ~14-instruction IEEE division chain
-        double rinv = __builtin_amdgcn_rcp(d);
-        rinv = fma(fma(-d, rinv, 1.0), rinv, rinv);
-        rinv = fma(fma(-d, rinv, 1.0), rinv, rinv);
+        const double c1 = col[nw * 16 + nm];                  // a[j+1][j]; all the LDS reads of the step go out together
+        const double dprev = diagp[j & 1];
+        asm volatile("" : "+v"(cr));                          // (keeps the read out of a branch on the lane predicate below)
         const double f = (lane > j) ? cr * rinv : 0.0;
-        if constexpr (j + 1 < NB) {
-            if (w == nw) {
-                a[nm] = fma(-f, sc[nm], a[nm]);
-                colp[(j + 1) & 1][self] = a[nm];
-            }
+        // every wave updates its columns w + 4 nm and w + 4 pm first; the owners' values go out
+        if constexpr (has_n) {
+            a[nm] = fma(-f, (nm == om && w <= ow) ? 0.0 : sc[nm], a[nm]);
+            *((w == nw) ? pub_col[(j + 1) & 1] : pub_none) = a[nm];
         }
+        if constexpr (has_p && pm != nm) a[pm] = fma(-f, sc[pm], a[pm]);
+        if constexpr (has_p) *((w == pw && lane == j + 2) ? &diagp[(j + 1) & 1] : pub_none) = a[pm];
         __builtin_amdgcn_sched_barrier(0);
+        double rnext = 0.0;
+        if constexpr (has_n) {
+            const double dn = checked_pivot(fma(-(c1 * rinv), c1, dprev), j + 1);
+            if (lane == j + 1) dreg = dn;
+            rnext = reciprocal(dn);
+        }
 #pragma unroll
         for (int m = 0; m < 16; ++m)
-            if (m >= om) {
-                const double mult = (m == om && w <= ow) ? 0.0 : sc[m];
-                if (m != nm || w != nw) a[m] = fma(-f, mult, a[m]);
-            }
-        // keep step j's updates in step j (an opaque use): sunk towards their first reader they pile up hundreds of
-        // live multipliers and the kernel spills
+            if (m >= om && !(has_n && m == nm) && !(has_p && m == pm))
+                a[m] = fma(-f, (m == om && w <= ow) ? 0.0 : sc[m], a[m]);
+        rinv = rnext;
+        // keep step j's work in step j (opaque uses): sunk towards their first readers the updates pile up hundreds of
+        // live multipliers (the kernel spills) and the tail of the reciprocal lands behind the next barrier
+        asm volatile("" : "+v"(rinv));
 #pragma unroll
         for (int m = 0; m < 16; ++m)
             if (m >= om) asm volatile("" : "+v"(a[m]));
     };
     unroll_ints(std::make_integer_sequence<int, NB>{}, factor_column);
+    if (b == 0 && t == 0 && first_bad) atomicCAS(info, 0, (int)k0 + first_bad);
     GPT_TRACE(2);
     const double dsqv = sqrt(dreg), dinvv = 1.0 / dsqv;     // lane l: sqrt / inverse sqrt of pivot l
     if (w == 0) dinv[lane] = dinvv;
