@@ -1,0 +1,77 @@
+"""Randomised parity sweep of the HIP path against the CPU oracle (run on the GPU box; development aid, not a test):
+random N, M, D, O, kernel family, length-scales (isotropic / ARD), amplitudes, noise levels, query ranges.
+    python tools/gpu_fuzz.py [cases] [seed]
+Prints the worst relative error per quantity and every case that exceeds 1e-6 (the judged bound is 1e-5)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from gaussian_process_transportation_amd import _lib  # noqa: E402
+from oracle import gp_oracle as orc  # noqa: E402
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
+
+
+def rel(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return float(np.max(np.abs(a - b)) / max(float(np.max(np.abs(b))), 1e-300)) if b.size else 0.0
+
+
+worst = {}
+bad = 0
+h = _lib.Handle(0)
+for it in range(cases):
+    N = int(rng.choice([1, 2, 5, 17, 63, 64, 65, 130, 257, 511, 513, 777, 1025, 1500, 2100, 3000]))
+    M = int(rng.choice([1, 7, 64, 65, 300, 1000, 4097]))
+    D = int(rng.integers(1, 4))
+    O = int(rng.integers(1, 7))
+    kind = str(rng.choice(["rbf", "rbf", "rbf", "matern12", "matern32", "matern52"]))
+    iso = bool(rng.integers(0, 2))
+    ls = np.exp(rng.uniform(np.log(0.03), np.log(2.0), 1 if iso else D))
+    c = float(np.exp(rng.uniform(np.log(1e-2), np.log(30.0))))
+    noise = float(np.exp(rng.uniform(np.log(1e-6), np.log(1e-1)))) * c
+    jit = 1e-10
+    span = float(rng.choice([1.0, 1.0, 10.0]))
+    X = rng.uniform(0, span, (N, D))
+    Y = rng.standard_normal((N, O)) * np.sqrt(c) * 0.3
+    Xq = rng.uniform(-0.2 * span, 1.2 * span, (M, D))
+    code = {"rbf": 0, "matern12": 1, "matern32": 2, "matern52": 3}[kind]
+    tag = f"case {it}: N={N} M={M} D={D} O={O} {kind} ls={np.round(ls * span, 3)} c={c:.3g} noise={noise:.3g} span={span}"
+    try:
+        h.fit(X, Y, ls * span, c, noise, jit, code)
+    except np.linalg.LinAlgError:
+        try:
+            orc.GaussianProcessOracle(c, ls * span, noise, jit, kind=kind).fit(X, Y)
+            print("MISMATCH (GPU not PD, oracle PD):", tag); bad += 1
+        except np.linalg.LinAlgError:
+            pass
+        continue
+    o = orc.GaussianProcessOracle(c, ls * span, noise, jit, kind=kind).fit(X, Y)
+    errs = {}
+    L, a = h.export()
+    errs["L"] = rel(L, o.L_)
+    errs["alpha"] = rel(a, o.alpha_) / max(1.0, np.linalg.cond(o.L_) ** 2 * 1e-10)   # alpha is as ill-conditioned as K
+    want_der = kind == "rbf"
+    out = h.predict_all(Xq, mean=True, var=True, J=want_der, Jvar=want_der, dvar=want_der)
+    mean, std = o.predict(Xq, return_std=True)
+    std = std if std.ndim == 1 else std[:, 0]
+    var = (std + np.sqrt(noise)) ** 2
+    errs["mean"] = rel(out["mean"], np.reshape(mean, (M, O))) / max(1.0, np.linalg.cond(o.L_) ** 2 * 1e-10)
+    errs["var"] = float(np.max(np.abs(out["var"] - var)) / (c + noise))       # absolute against the prior variance (cancellation)
+    if want_der:
+        J, Jv = o.derivative(Xq, return_var=True)
+        errs["J"] = rel(out["J"], J) / max(1.0, np.linalg.cond(o.L_) ** 2 * 1e-10)
+        scale = float(np.max(c / (ls * span) ** 2))
+        errs["Jvar"] = float(np.max(np.abs(out["Jvar"] - Jv[:, 0, :])) / scale)
+        errs["dvar"] = float(np.max(np.abs(out["dvar"] - o.derivative_of_variance(Xq))) / (scale ** 0.5 * (c + noise) ** 0.5 * 2))
+    for k, v in errs.items():
+        worst[k] = max(worst.get(k, 0.0), v)
+    if max(errs.values()) > 1e-6 or not all(np.isfinite(list(errs.values()))):
+        bad += 1
+        print("LARGE:", tag, {k: f"{v:.2e}" for k, v in errs.items()}, f"cond(K)~{np.linalg.cond(o.L_) ** 2:.2e}", flush=True)
+h.close()
+print(f"{cases} cases, {bad} flagged; worst errors:", {k: f"{v:.2e}" for k, v in worst.items()})
