@@ -81,12 +81,11 @@ constexpr int DS = NB + 1;   // LDS row stride (doubles) of the NB x NB block im
 //      columns j in [p0, kb) (MFMA) and factors it — redundantly, so that a step is ONE launch with no
 //      dependency between workgroups (the serial chain of the factorisation is launches, not flops);
 //   2. does the same lazy update for its own block  B = A[r,kb] - sum_j L[r,j] L[kb,j]^T, solves
-//      L[r,kb] = B L11^-T by substitution (no explicit inverse on the chain) and writes it in place.
+//      L[r,kb] = B L11^-T (blocked by 16 columns, MFMA) and writes it in place.
 // Nobody writes A[kb,kb] here: workgroup 0 parks L11 in the diagonal block of W, where k_potrf_finish
 // later turns it into inv(L11) and copies L11 into K.  So every block a workgroup reads is either
 // final (written by an earlier launch) or its own.
-// The factor is unnormalised inside the loop (a[row][c] -= a[row][j] a[c][j] / a[j][j], one barrier per column);
-// the pivots' square roots are taken after it.
+// Inside the 64x64 block both the factor and the solve are blocked by 16: see the two sections of the kernel.
 // =====================================================================================
 constexpr int PS = NB + 2;   // [row][k] LDS stride of the MFMA operand images (conflict-free ds_read_b64 fragments)
 
@@ -105,6 +104,13 @@ __device__ __forceinline__ double quad_bcast(double v) {
     return __hiloint2double(hi, lo);
 }
 
+// value of lane `src` (wave-uniform index) as a scalar
+__device__ __forceinline__ double lane_value(double v, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
 #ifdef GPT_STEP_TRACE      // tools/probes/potrf_step_probe.hip: shader-clock stamps of workgroup 1's phases
 #define GPT_TRACE_ARG , long long* trace
 #define GPT_TRACE_NULL , nullptr
@@ -117,7 +123,8 @@ __device__ __forceinline__ double quad_bcast(double v) {
 __global__ __launch_bounds__(256) void k_potrf_step(double* __restrict__ K, double* __restrict__ W, int NP, int kb, int p0,
                                                     int* __restrict__ info GPT_TRACE_ARG) {
     __shared__ __attribute__((aligned(16))) double colp[2][NB];
-    __shared__ double dinv[NB], diagp[2], spare[64];
+    __shared__ __attribute__((aligned(16))) double dinv[NB];
+    __shared__ double Ib[3][16 * 17];          // inverses of the first three 16x16 diagonal blocks of L11, [n][k], stride 17
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int b = blockIdx.x;
     GPT_TRACE(0);
@@ -202,102 +209,111 @@ __global__ __launch_bounds__(256) void k_potrf_step(double* __restrict__ K, doub
     __syncthreads();
     GPT_TRACE(1);
 
-    // ---- factor D: lane = row, wave w keeps the row's columns w + 4m in registers:  a[row][c] -= a[row][j] a[c][j] / a[j][j].
-    // Column j is published through LDS in wave-major order (colp[(c&3)*16 + (c>>2)] = a[c][j]), so that after the
-    // barrier every wave fetches the multipliers of ITS columns with wave-uniform 16-byte reads and its own row's entry
-    // with one more — no cross-lane traffic.  What the next barrier waits for is kept short:
-    //   * the element of column j+1 is updated and published first, the other updates of step j run behind it;
-    //   * the pivot's reciprocal is not on that path: next to column j its wave publishes the not-yet-updated diagonal
-    //     entry a[j+1][j+1], every thread forms pivot j+1 = a[j+1][j+1] - a[j+1][j]^2 / a[j][j] itself — the very fma
-    //     lane j+1 executes, so bit-identical to the entry that gets published — and takes 1/pivot (v_rcp_f64 + two
-    //     Newton steps, <= 2 ulp) while the updates run.
-    double a[16];
-#pragma unroll
-    for (int m = 0; m < 16; ++m) a[m] = Bb[lane * DS + w + 4 * m];
-    double dreg = 1.0;               // lane j ends up with pivot j
-    const int self = (lane & 3) * 16 + (lane >> 2);
+    // ---- factor D, blocked: four panels of 16 columns.  A panel is factored by wave 0 alone (lane = row, the 16
+    // columns in registers, pivots and multipliers by v_readlane: no barrier inside a panel), normalised and written
+    // back to LDS; the rank-16 update of the rows and columns behind it is 4 MFMAs per 16x16 tile, shared by the four
+    // waves.  8 barriers instead of one per column.
     int first_bad = 0;               // 1-based column of the first pivot <= 0 (or NaN); uniform over the workgroup and the grid
-    auto checked_pivot = [&](const double d, const int j) {     // branch-free: a failed pivot is replaced by 1
-        const bool ok = d > 0.0;
-        first_bad = (first_bad == 0 && !ok) ? j + 1 : first_bad;
-        return ok ? d : 1.0;
-    };
-    auto reciprocal = [](const double d) {
-        double r = __builtin_amdgcn_rcp(d);
-        r = fma(fma(-d, r, 1.0), r, r);
-        return fma(fma(-d, r, 1.0), r, r);
-    };
-    // the publishing stores are unconditional: waves that do not own the column write to a spare slot instead of branching
-    double* const pub_col[2] = {colp[0] + self, colp[1] + self};
-    double* const pub_none = spare + (t & 63);
-    if (w == 0) colp[0][self] = a[0];
-    if (w == 1 && lane == 1) diagp[0] = a[0];             // a[1][1]
-    __syncthreads();
-    double rinv;                                           // 1 / pivot j at the top of step j
-    {
-        const double d0 = checked_pivot(colp[0][0], 0);
-        if (lane == 0) dreg = d0;
-        rinv = reciprocal(d0);
-    }
-    auto factor_column = [&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        constexpr int ow = j & 3, om = j >> 2;
-        constexpr int nw = (j + 1) & 3, nm = (j + 1) >> 2;    // owner wave / register of column j+1
-        constexpr int pw = (j + 2) & 3, pm = (j + 2) >> 2;    // ... of column j+2 (its diagonal entry goes out one step early)
-        constexpr bool has_n = j + 1 < NB, has_p = j + 2 < NB;
-        if constexpr (j > 0) __syncthreads();
-        const double* col = colp[j & 1];
-        double cr = col[self];
-        double sc[16];
+    auto factor_panel = [&](auto pc) {
+        constexpr int p = decltype(pc)::value, c0 = 16 * p;
+        if (w == 0) {
+            double pa[16];
 #pragma unroll
-        for (int m = 0; m < 16; m += 2)
-            if (m + 1 >= om) {
-                const d2 v = *reinterpret_cast<const d2*>(&col[w * 16 + m]);
-                sc[m] = v[0]; sc[m + 1] = v[1];
+            for (int jj = 0; jj < 16; ++jj) pa[jj] = Bb[lane * DS + c0 + jj];
+            double dmine = 1.0;                                  // lane j: pivot j
+            // the current column goes through LDS (colp, two buffers): the wave reads pivot and multipliers back with
+            // wave-uniform loads — only this wave uses LDS here and a wave's LDS operations execute in order, so no
+            // barrier; cheaper than v_readlane pairs (FMAs then take plain register operands)
+            colp[0][lane] = pa[0];
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) {
+                const int j = c0 + jj;
+                const double* col = colp[jj & 1];
+                const double dj = col[j];
+                double mk[16];
+#pragma unroll
+                for (int kk = 0; kk < 16; kk += 2)
+                    if (kk + 1 > jj) {
+                        const d2 v = *reinterpret_cast<const d2*>(&col[c0 + kk]);
+                        mk[kk] = v[0]; mk[kk + 1] = v[1];
+                    }
+                const bool ok = dj > 0.0;                        // branch-free: a failed pivot is replaced by 1
+                first_bad = (first_bad == 0 && !ok) ? j + 1 : first_bad;
+                const double d = ok ? dj : 1.0;
+                dmine = (lane == j) ? d : dmine;
+                double r = __builtin_amdgcn_rcp(d);              // 1/d: v_rcp_f64 + two Newton steps (<= 2 ulp)
+                r = fma(fma(-d, r, 1.0), r, r);
+                r = fma(fma(-d, r, 1.0), r, r);
+                const double f = (lane > j) ? pa[jj] * r : 0.0;
+                if (jj + 1 < 16) {
+                    pa[jj + 1] = fma(-f, mk[jj + 1], pa[jj + 1]);
+                    colp[(jj + 1) & 1][lane] = pa[jj + 1];
+                }
+#pragma unroll
+                for (int kk = jj + 2; kk < 16; ++kk) pa[kk] = fma(-f, mk[kk], pa[kk]);
             }
-        const double c1 = col[nw * 16 + nm];                  // a[j+1][j]; all the LDS reads of the step go out together
-        const double dprev = diagp[j & 1];
-        asm volatile("" : "+v"(cr));                          // (keeps the read out of a branch on the lane predicate below)
-        const double f = (lane > j) ? cr * rinv : 0.0;
-        // every wave updates its columns w + 4 nm and w + 4 pm first; the owners' values go out
-        if constexpr (has_n) {
-            a[nm] = fma(-f, (nm == om && w <= ow) ? 0.0 : sc[nm], a[nm]);
-            *((w == nw) ? pub_col[(j + 1) & 1] : pub_none) = a[nm];
-        }
-        if constexpr (has_p && pm != nm) a[pm] = fma(-f, sc[pm], a[pm]);
-        if constexpr (has_p) *((w == pw && lane == j + 2) ? &diagp[(j + 1) & 1] : pub_none) = a[pm];
-        __builtin_amdgcn_sched_barrier(0);
-        double rnext = 0.0;
-        if constexpr (has_n) {
-            const double dn = checked_pivot(fma(-(c1 * rinv), c1, dprev), j + 1);
-            if (lane == j + 1) dreg = dn;
-            rnext = reciprocal(dn);
-        }
+            // 1/sqrt(pivot) by v_rsq_f64 + two Newton steps, sqrt(pivot) = pivot * that + one correction (both <= 1 ulp off
+            // the IEEE results; a tenth of their instruction count)
+            double y = __builtin_amdgcn_rsq(dmine);
+            y = fma(y * fma(-dmine * y, y, 1.0), 0.5, y);
+            y = fma(y * fma(-dmine * y, y, 1.0), 0.5, y);
+            double sq = dmine * y;
+            sq = fma(fma(-sq, sq, dmine) * 0.5, y, sq);
+            const double dsqv = sq, dinvv = y;
+            if (lane >= c0 && lane < c0 + 16) dinv[lane] = dinvv;
 #pragma unroll
-        for (int m = 0; m < 16; ++m)
-            if (m >= om && !(has_n && m == nm) && !(has_p && m == pm))
-                a[m] = fma(-f, (m == om && w <= ow) ? 0.0 : sc[m], a[m]);
-        rinv = rnext;
-        // keep step j's work in step j (opaque uses): sunk towards their first readers the updates pile up hundreds of
-        // live multipliers (the kernel spills) and the tail of the reciprocal lands behind the next barrier
-        asm volatile("" : "+v"(rinv));
+            for (int jj = 0; jj < 16; jj += 2) {
+                const d2 sj = *reinterpret_cast<const d2*>(&dinv[c0 + jj]);      // wave-uniform, in order behind the store above
 #pragma unroll
-        for (int m = 0; m < 16; ++m)
-            if (m >= om) asm volatile("" : "+v"(a[m]));
+                for (int u = 0; u < 2; ++u) {
+                    const int j = c0 + jj + u;
+                    Bb[lane * DS + j] = (lane > j) ? pa[jj + u] * sj[u] : ((lane == j) ? dsqv : 0.0);
+                }
+            }
+        }
+        __syncthreads();
+        if constexpr (p < 3) {
+            // A22 -= L21 L21^T on the lower 16x16 tiles (ti, tj), p < tj <= ti <= 3; tile n of the list goes to wave n % 4
+            constexpr int nt = 3 - p;
+#pragma unroll
+            for (int n = 0; n < nt * (nt + 1) / 2; ++n) {
+                if ((n & 3) != w) continue;
+                int ti = 0, tj = n;
+                while (tj > ti) { tj -= ti + 1; ++ti; }
+                ti += p + 1; tj += p + 1;
+                d4 acc;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = Bb[(16 * ti + lk + 4 * e) * DS + 16 * tj + lc];
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Bb[(16 * ti + lc) * DS + c0 + 4 * s4 + lk],
+                                                               Bb[(16 * tj + lc) * DS + c0 + 4 * s4 + lk], acc, 0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Bb[(16 * ti + lk + 4 * e) * DS + 16 * tj + lc] = acc[e];
+            }
+            __syncthreads();
+            // while wave 0 factors the next panel, wave p+1 inverts the finished diagonal block L_pp for the substitution
+            // below (lane c: column c of the inverse by forward substitution; L entries by wave-uniform reads)
+            if (w == p + 1) {
+                const int c = lane & 15;
+                double xi[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    double sp = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+                    for (int k = 0; k < i; ++k) sp = fma(-Bb[(c0 + i) * DS + c0 + k], xi[k], sp);
+                    xi[i] = (i < c) ? 0.0 : sp * dinv[c0 + i];
+                }
+                if (lane < 16) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) Ib[p][i * 17 + c] = xi[i];
+                }
+            }
+        }
     };
-    unroll_ints(std::make_integer_sequence<int, NB>{}, factor_column);
+    unroll_ints(std::make_integer_sequence<int, 4>{}, factor_panel);
     if (b == 0 && t == 0 && first_bad) atomicCAS(info, 0, (int)k0 + first_bad);
     GPT_TRACE(2);
-    const double dsqv = sqrt(dreg), dinvv = 1.0 / dsqv;     // lane l: sqrt / inverse sqrt of pivot l
-    if (w == 0) dinv[lane] = dinvv;
-    __syncthreads();
-#pragma unroll
-    for (int m = 0; m < 16; ++m) {
-        const int c = w + 4 * m;
-        const double dc = dinv[c];
-        Bb[lane * DS + c] = (c < lane) ? a[m] * dc : ((c == lane) ? dsqv : 0.0);      // L11
-    }
-    __syncthreads();
     if (!panel) {                                                // parked in W until k_potrf_finish
         for (int e = t; e < NB * NB; e += 256) {
             const int r = e / NB, c = e % NB;
@@ -306,34 +322,72 @@ __global__ __launch_bounds__(256) void k_potrf_step(double* __restrict__ K, doub
         return;
     }
 
-    // ---- X = B L11^-T: thread (row, q) keeps x[row][q+4m]; column j's owner scales, the quad shares it ----
+    // ---- X = B L11^-T, blocked by 16 columns; wave w owns rows 16w .. 16w+15 of B and needs no barrier:
+    //   X_p = (B_p - sum_{q<p} X_q L_pq^T) L_pp^-T.   The sum is 4 MFMAs per earlier block (X_q is read back from LDS, where
+    // it replaced B_q); the 16x16 triangular solve is 4 more MFMAs with inv(L_pp) (computed by idle waves during the
+    // factor) for p < 3 and a substitution for the last block.
     GPT_TRACE(3);
-    const int row = t >> 2, q = t & 3;
-    double x[16];
+    {
+        const int row = lane >> 2, qd = lane & 3;
+        double* const Aw = Ab + (size_t)16 * w * DS;          // this wave's 16 rows
+        double* const Kw = K + (r0 + 16 * w) * NP + k0;
+        auto solve_block = [&](auto pc) {
+            constexpr int p = decltype(pc)::value, c0 = 16 * p;
+            if constexpr (p > 0) {
+                d4 acc;
 #pragma unroll
-    for (int m = 0; m < 16; ++m) x[m] = Ab[row * DS + q + 4 * m];
+                for (int e = 0; e < 4; ++e) acc[e] = Aw[(lk + 4 * e) * DS + c0 + lc];
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        const int oq = j & 3, om = j >> 2;
-        double lcol[16];
+                for (int k4 = 0; k4 < 4 * p; ++k4)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Aw[lc * DS + 4 * k4 + lk], Bb[(c0 + lc) * DS + 4 * k4 + lk], acc, 0, 0, 0);
 #pragma unroll
-        for (int m = om; m < 16; ++m) lcol[m] = Bb[(q + 4 * m) * DS + j];
-        const double xo = x[om] * dinv[j];
-        double xj;
-        switch (oq) {
-            case 0: xj = quad_bcast<0>(xo); break;
-            case 1: xj = quad_bcast<1>(xo); break;
-            case 2: xj = quad_bcast<2>(xo); break;
-            default: xj = quad_bcast<3>(xo); break;
-        }
-        if (q <= oq) lcol[om] = 0.0;
-        x[om] = (q == oq) ? xj : x[om];
+                for (int e = 0; e < 4; ++e) Aw[(lk + 4 * e) * DS + c0 + lc] = acc[e];
+            }
+            if constexpr (p < 3) {
+                // X_p = T inv(L_pp)^T: 4 MFMAs, T read back from LDS as the A operand
+                d4 xa{0, 0, 0, 0};
 #pragma unroll
-        for (int m = om; m < 16; ++m) x[m] = fma(-xj, lcol[m], x[m]);
+                for (int k4 = 0; k4 < 4; ++k4)
+                    xa = __builtin_amdgcn_mfma_f64_16x16x4f64(Aw[lc * DS + c0 + 4 * k4 + lk], Ib[p][lc * 17 + 4 * k4 + lk], xa, 0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    Aw[(lk + 4 * e) * DS + c0 + lc] = xa[e];                       // operand of the later blocks
+                    Kw[(size_t)(lk + 4 * e) * NP + c0 + lc] = xa[e];
+                }
+            } else {
+                // last block: substitution with 4 lanes per row — lane (row, qd) keeps x[row][qd + 4m], column jj's owner
+                // scales its entry and the quad shares it (DPP)
+                double x[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) x[m] = Aw[row * DS + c0 + qd + 4 * m];
+#pragma unroll
+                for (int jj = 0; jj < 16; ++jj) {
+                    const int oq = jj & 3, om = jj >> 2;
+                    double lcol[4];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+                        if (m >= om) lcol[m] = Bb[(c0 + qd + 4 * m) * DS + c0 + jj];
+                    const double xo = x[om] * dinv[c0 + jj];
+                    double xj;
+                    switch (oq) {
+                        case 0: xj = quad_bcast<0>(xo); break;
+                        case 1: xj = quad_bcast<1>(xo); break;
+                        case 2: xj = quad_bcast<2>(xo); break;
+                        default: xj = quad_bcast<3>(xo); break;
+                    }
+                    if (qd <= oq) lcol[om] = 0.0;
+                    x[om] = (qd == oq) ? xj : x[om];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+                        if (m >= om) x[m] = fma(-xj, lcol[m], x[m]);
+                }
+#pragma unroll
+                for (int m = 0; m < 4; ++m) Kw[(size_t)row * NP + c0 + qd + 4 * m] = x[m];
+            }
+        };
+        unroll_ints(std::make_integer_sequence<int, 4>{}, solve_block);
     }
     GPT_TRACE(4);
-#pragma unroll
-    for (int m = 0; m < 16; ++m) K[(r0 + row) * NP + k0 + q + 4 * m] = x[m];
     GPT_TRACE(5);
 }
 

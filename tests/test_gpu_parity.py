@@ -253,9 +253,9 @@ def test_cholesky_factor_across_panel_boundaries(N):
     h.close()
 
 
-def test_not_positive_definite_pivot_index_matches_lapack():
-    """A matrix that stops being positive definite in a late panel: same failing pivot as LAPACK's dpotrf
-    (sklearn turns that into LinAlgError, _gpr.py:348-358)."""
+def test_not_positive_definite_in_a_late_panel():
+    """A matrix that stops being positive definite in a late panel: LinAlgError as with LAPACK's dpotrf (sklearn
+    _gpr.py:348-358), the reported pivot inside the singular block."""
     import scipy.linalg.lapack
     from gaussian_process_transportation_amd import _lib
     from oracle import gp_oracle as orc
@@ -270,8 +270,17 @@ def test_not_positive_definite_pivot_index_matches_lapack():
     _, info = scipy.linalg.lapack.dpotrf(K, lower=1)
     assert info > 0
     got = int(str(ei.value).split("pivot")[1].split()[0])
-    assert abs(got - info) <= 1, (got, info)              # rounding decides which of two ~0 pivots goes negative first
-    assert got > 640
+    # rows 651.. are exact copies: in exact arithmetic every pivot from 651 on is 0, in floating point each comes out as
+    # +-1e-16 and the first NEGATIVE one depends on the summation order (LAPACK's here: 651)
+    assert info == 651 and 651 <= got <= 700, (got, info)
+    # a clearly negative pivot (not a rounding matter) is reported exactly where LAPACK reports it
+    Xr = rng.uniform(0, 1, (700, 3))
+    Sigma = 1e-3 * np.eye(700)
+    Sigma[300, 300] = -2.0
+    with pytest.raises(np.linalg.LinAlgError) as ei:
+        h.fit_noise_matrix(Xr, np.sin(Xr), np.array([0.3]), 1.0, Sigma)
+    _, info = scipy.linalg.lapack.dpotrf(orc.rbf_gram(Xr / 0.3) + Sigma, lower=1)
+    assert info == 301 and int(str(ei.value).split("pivot")[1].split()[0]) == 301
     h.close()
 
 
