@@ -250,10 +250,14 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlan pl, cons
     const double lnc = p.lnc;
     const int nbi = pl.nbi;
     // A stream in d2 units: element (step S, group g, q, lane) at ((S*8 + g)*2 + q)*64 + lane
-    const d2* const wbase = reinterpret_cast<const d2*>(Wf) + (size_t)g * 128 + lane;
+    // uniform base + per-lane 32-bit offset (scalar-base addressing: no 64-bit VALU address arithmetic, and no VALU
+    // writes into registers that loads are still in flight to)
+    const d2* const wuni = reinterpret_cast<const d2*>(Wf) + (size_t)g * 128;
+    const int wlane = lane;
     constexpr size_t STEP_D2 = WT_STEP_DOUBLES / 2;   // 1024
     // this workgroup's B image in d2 units: k-step s, lane l at (s*64 + l)*2 (+1)
-    d2* const bimg = reinterpret_cast<d2*>(bscratch) + (size_t)blockIdx.x * ((size_t)p.NP * 32) + (size_t)lane * 2;
+    d2* const buni = reinterpret_cast<d2*>(bscratch) + (size_t)blockIdx.x * ((size_t)p.NP * 32);
+    const int blane = lane * 2;
 
     for (int64_t piece = 0;; ++piece) {
         int64_t cb, slot; int lo, hi;
@@ -297,7 +301,8 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlan pl, cons
                     const double* xp = Xs + (size_t)(k4 * 4 + lk) * 4;
                     gx[0] = xp[0]; gx[1] = xp[1]; gx[2] = xp[2];
                 } else {
-                    bl[0] = bimg[(size_t)k4 * 128]; bl[1] = bimg[(size_t)k4 * 128 + 1];
+                    const d2* src = buni + (size_t)k4 * 128;
+                    bl[0] = src[blane]; bl[1] = src[blane + 1];
                 }
             };
             auto produce = [&](const int buf, const int k4) {   // B fragments of k-step k4 -> LDS (+ scratch)
@@ -315,7 +320,7 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlan pl, cons
                         b[t] = (NCOMP == 1) ? kv : kv * (cbv + cd[0] * d0 + cd[1] * d1 + cd[2] * d2_);
                     }
                     *reinterpret_cast<d4*>(dstl) = b;
-                    d2* dst = bimg + (size_t)k4 * 128;
+                    d2* dst = buni + (size_t)k4 * 128 + blane;
                     dst[0] = d2{b[0], b[1]};
                     dst[1] = d2{b[2], b[3]};
                 } else {
@@ -333,7 +338,7 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlan pl, cons
                 }
             }
             d2 a_nxt[2];
-            a_nxt[0] = wbase[S_ib * STEP_D2]; a_nxt[1] = wbase[S_ib * STEP_D2 + 64];   // step 0 is active for every group
+            a_nxt[0] = (wuni + S_ib * STEP_D2)[wlane]; a_nxt[1] = (wuni + S_ib * STEP_D2)[wlane + 64];   // step 0 is active for every group
             __syncthreads();
             d4 acc[4][4];
 #pragma unroll
@@ -346,35 +351,62 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlan pl, cons
             // OUT of the lock-step LDS pipeline: see below.  The generating sweep keeps it in (its fragments are
             // not in the scratch image yet).
             const int nchunks = (GEN ? nk4 : ib * WT_K4) / VAR_CH;
-            for (int ch = 0; ch < nchunks; ++ch) {
+            // Sources of the fills inside the loop, as loop-carried per-lane pointers (k-step VAR_CH + w first, then
+            // VAR_SUB further each time): an address recomputed from the k-step lands in whatever registers are free —
+            // the previous fill's destination registers — and that write-after-load made hipcc drain vmcnt to 0 (and with
+            // it the A fragments in flight) at the top of every sub-chunk.
+            const d2* bsrc = buni + (size_t)(VAR_CH + w) * 128 + blane;
+            const double* xsrc = Xs + (size_t)((VAR_CH + w) * 4 + lk) * 4;
+            auto fetch_next = [&]() {
+                if (GEN) {
+                    gx[0] = xsrc[0]; gx[1] = xsrc[1]; gx[2] = xsrc[2];
+                    xsrc += VAR_SUB * 16;
+                } else {
+                    bl[0] = bsrc[0]; bl[1] = bsrc[1];
+                    bsrc += VAR_SUB * 128;
+                }
+            };
+            // the chunk body exists twice — with and without the fill of the following chunk — so that "is there a next
+            // chunk" is no branch (and no join in front of the first MFMAs of a sub-chunk) inside it
+            auto chunk = [&](auto more_tag, const int ch) {
+                constexpr bool more = decltype(more_tag)::value;
                 const int cur = ch & 1;
-                const bool more = (ch + 1 < nchunks);
                 d4 b_nxt = *reinterpret_cast<const d4*>(Bs(cur, 0));    // B fragments are read one k-step ahead
                 for (int sub = 0; sub < VAR_SUBS; ++sub) {
                     const int k0 = ch * VAR_CH + sub * VAR_SUB;                 // first k-step of this sub-chunk
                     const int kn = (ch + 1) * VAR_CH + sub * VAR_SUB + w;       // the k-step this wave fills meanwhile
-                    if (more) fetch(kn);
+                    if (more) fetch_next();
                     const bool active = (k0 < my_limit) && !(GPT_ABL == 3 && k0 >= ib * WT_K4);   // my_limit is a multiple of 16: all or nothing
                     auto step = [&](const int s) {
                         const int k4 = k0 + s;
                         const d2 a01 = a_nxt[0], a23 = a_nxt[1];
                         const d4 b = b_nxt;
                         const size_t Sn = S_ib + ((k4 + 1 < my_limit) ? (k4 + 1) : k4);
-                        if (GPT_ABL != 2) { a_nxt[0] = wbase[Sn * STEP_D2]; a_nxt[1] = wbase[Sn * STEP_D2 + 64]; }
+                        if (GPT_ABL != 2) { a_nxt[0] = (wuni + Sn * STEP_D2)[wlane]; a_nxt[1] = (wuni + Sn * STEP_D2)[wlane + 64]; }
                         const int sn = sub * VAR_SUB + s + 1;
                         if (sn < VAR_CH) b_nxt = *reinterpret_cast<const d4*>(Bs(cur, sn));
                         if (GPT_ABL == 5) { asm volatile("" :: "v"(a01), "v"(a23), "v"(b)); return; }
                         GPT_MFMA16(acc, a01, a23, b);
                     };
-                    if (active) { step(0); step(1); }
-                    if (more && w < 4 && GPT_ABL != 4) produce(cur ^ 1, kn);
-                    if (active) { step(2); step(3); step(4); step(5); }
-                    if (more && w >= 4 && GPT_ABL != 4) produce(cur ^ 1, kn);
-                    if (active) { step(6); step(7); }
-                    else if (sub + 1 < VAR_SUBS) b_nxt = *reinterpret_cast<const d4*>(Bs(cur, (sub + 1) * VAR_SUB));
+                    // The fill of the next chunk sits INSIDE the active / idle paths, not behind their join: vmcnt counts in
+                    // issue order, and behind a join hipcc has to wait for vmcnt(0) — which also waits for the A fragments
+                    // the steps just before have requested (a full L2 round trip per sub-chunk); inside the straight-line
+                    // path it waits for the fill's own loads only (vmcnt(4) / vmcnt(12)).
+                    if (active) {
+                        step(0); step(1);
+                        if (more && w < 4 && GPT_ABL != 4) produce(cur ^ 1, kn);
+                        step(2); step(3); step(4); step(5);
+                        if (more && w >= 4 && GPT_ABL != 4) produce(cur ^ 1, kn);
+                        step(6); step(7);
+                    } else {
+                        if (more && GPT_ABL != 4) produce(cur ^ 1, kn);
+                        if (sub + 1 < VAR_SUBS) b_nxt = *reinterpret_cast<const d4*>(Bs(cur, (sub + 1) * VAR_SUB));
+                    }
                 }
                 if (GPT_ABL != 1) __syncthreads();
-            }
+            };
+            for (int ch = 0; ch + 1 < nchunks; ++ch) chunk(std::true_type{}, ch);
+            if (nchunks > 0) chunk(std::false_type{}, nchunks - 1);
             if (!GEN && GPT_ABL != 3) {
                 // Diagonal tile of a reload sweep, barrier-free: every wave runs its own 16 (g + 1) k-steps with A from
                 // Wf and B straight from the scratch image (both one MFMA block ahead; program order pinned with
@@ -383,15 +415,15 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlan pl, cons
                 // instead of 0.75.
                 const int kd0 = ib * WT_K4;                              // first k-step of the diagonal tile
                 const int limit = 16 * (g + 1);                          // even
-                const d2* ap = wbase + (S_ib + kd0) * STEP_D2;
-                const d2* bp = bimg + (size_t)kd0 * 128;
+                const d2* ap = wuni + (S_ib + kd0) * STEP_D2;
+                const d2* bp = buni + (size_t)kd0 * 128;
                 auto ldA = [&](d2 (&a)[2], const int k) {
                     const int kk = k < limit ? k : limit - 1;            // clamped: redundant, in bounds
-                    a[0] = ap[(size_t)kk * STEP_D2]; a[1] = ap[(size_t)kk * STEP_D2 + 64];
+                    a[0] = (ap + (size_t)kk * STEP_D2)[wlane]; a[1] = (ap + (size_t)kk * STEP_D2)[wlane + 64];
                 };
                 auto ldB = [&](d2 (&b)[2], const int k) {
                     const int kk = k < limit ? k : limit - 1;
-                    b[0] = bp[(size_t)kk * 128]; b[1] = bp[(size_t)kk * 128 + 1];
+                    b[0] = (bp + (size_t)kk * 128)[blane]; b[1] = (bp + (size_t)kk * 128)[blane + 1];
                 };
                 d2 a0[2], a1[2], b0[2], b1[2];
                 ldA(a0, 0); ldA(a1, 1); ldB(b0, 0);
