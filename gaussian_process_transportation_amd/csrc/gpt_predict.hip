@@ -153,7 +153,7 @@ void launch_mean_jac(hipStream_t s, const KernelParams& p, const double* Xs, con
 //     4 MB at N=8192); the other sweeps reload them from there (2 KiB per k-step per workgroup) — so a
 //     block pays N exps per column, not N*(N/512+1)/2;
 //   * the A operand streams from the fragment-ordered image Wf with two 16-byte loads per lane and
-//     k-step, one step ahead; in the diagonal tile a wave skips the k-steps where its row group is
+//     k-step, two steps ahead; in the diagonal tile a wave skips the k-steps where its row group is
 //     entirely above the diagonal (wave g has 16 (g + 1) of 128), row groups paired (0,7)(1,6)(2,5)(3,4) on
 //     the SIMDs.  In the reload sweeps the diagonal tile runs OUTSIDE the lock-step LDS pipeline (every wave
 //     on its own, B straight from the scratch image), so the pairing balances it: 0.56 of a full tile
@@ -337,8 +337,9 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlan pl, cons
                     produce(0, j * VAR_SUB + w);
                 }
             }
-            d2 a_nxt[2];
+            d2 a_nxt[2], a_nx2[2];                         // A fragments of the next step and of the one after it
             a_nxt[0] = (wuni + S_ib * STEP_D2)[wlane]; a_nxt[1] = (wuni + S_ib * STEP_D2)[wlane + 64];   // step 0 is active for every group
+            a_nx2[0] = (wuni + (S_ib + 1) * STEP_D2)[wlane]; a_nx2[1] = (wuni + (S_ib + 1) * STEP_D2)[wlane + 64];   // and so is step 1
             __syncthreads();
             d4 acc[4][4];
 #pragma unroll
@@ -381,8 +382,10 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlan pl, cons
                         const int k4 = k0 + s;
                         const d2 a01 = a_nxt[0], a23 = a_nxt[1];
                         const d4 b = b_nxt;
-                        const size_t Sn = S_ib + ((k4 + 1 < my_limit) ? (k4 + 1) : k4);
-                        if (GPT_ABL != 2) { a_nxt[0] = (wuni + Sn * STEP_D2)[wlane]; a_nxt[1] = (wuni + Sn * STEP_D2)[wlane + 64]; }
+                        const int kl = my_limit - 1;
+                        const size_t Sn = S_ib + ((k4 + 2 < my_limit) ? (k4 + 2) : kl);
+                        a_nxt[0] = a_nx2[0]; a_nxt[1] = a_nx2[1];
+                        if (GPT_ABL != 2) { a_nx2[0] = (wuni + Sn * STEP_D2)[wlane]; a_nx2[1] = (wuni + Sn * STEP_D2)[wlane + 64]; }
                         const int sn = sub * VAR_SUB + s + 1;
                         if (sn < VAR_CH) b_nxt = *reinterpret_cast<const d4*>(Bs(cur, sn));
                         if (GPT_ABL == 5) { asm volatile("" :: "v"(a01), "v"(a23), "v"(b)); return; }
