@@ -1,6 +1,6 @@
-// Fit-side kernels for gfx950 (MI355X): RBF Gram assembly, blocked right-looking fp64
-// Cholesky with MFMA (v_mfma_f64_16x16x4_f64) panel/trailing updates, blocked triangular
-// inverse by recursive doubling, alpha = K^-1 Y, and packing of W = L^-1 into the
+// Fit-side kernels for gfx950 (MI355X): RBF / Matern Gram assembly, two-level blocked fp64
+// Cholesky (one launch per 64 columns, rank-128 trailing updates by MFMA v_mfma_f64_16x16x4_f64),
+// blocked triangular inverse by recursive doubling, alpha = K^-1 Y, and packing of W = L^-1 into the
 // MFMA-fragment-ordered tile stream the variance kernel consumes.
 //
 // What is replaced (reference, all CPU/LAPACK): sklearn/_gpr.py:346-364 (kernel_(X), +alpha on

@@ -3,7 +3,6 @@ compute without a GPU, and the host logic (affine alignment, transport algebra, 
 quaternions, sharding + gloo collectives) matches the golden vectors / oracle."""
 import os
 import re
-import sys
 
 import numpy as np
 import pytest

@@ -48,7 +48,6 @@ def check(N, M, D=3, O=3, ls=(0.1, 0.1, 0.1), seed=0):
 
 
 def timing(N, M):
-    import ctypes
     X, Y, Xq = orc.synthetic_problem(N, M)
     h = _lib.Handle(0)
     h.fit(X, Y, np.array([0.1] * 3), 0.1, 1e-4, 1e-10)
