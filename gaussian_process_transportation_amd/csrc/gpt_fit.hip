@@ -827,55 +827,62 @@ void launch_alpha(hipStream_t s, const double* W, const double* Y4, int N, int N
 // (the 64 rows one wave owns) the A operands of v_mfma_f64_16x16x4_f64 for its four 16-row tiles,
 // 16 B per lane and 2 KiB contiguous per wave and k4-step.
 // Rows/cols >= N (padding) are zeroed so padded sources never reach a variance.
-// One workgroup transposes a 128-row x 128-col sub-block through LDS (coalesced on both sides).
+// One workgroup transposes a 64-row x 128-col sub-block through LDS (coalesced on both sides).
 // =====================================================================================
 size_t wf_doubles(int NP) {
     const size_t nb = NP / WT;
     return nb * (nb + 1) / 2 * WT_TILE_DOUBLES + WT_STEP_DOUBLES;   // + one k4-step of prefetch overrun
 }
 
-constexpr int PK = 128;          // sub-block edge
-constexpr int PK_S = PK + 1;
+constexpr int PKR = 64;          // sub-block: one 64-row group ...
+constexpr int PKC = 128;         // ... x 128 columns (32 k4-steps); 65 KB of LDS, two workgroups per CU
+constexpr int PK_S = PKC + 1;
 
 __global__ __launch_bounds__(256) void k_pack_w(const double* __restrict__ W, int N, int NP, double* __restrict__ Wf) {
-    extern __shared__ __attribute__((aligned(16))) double tile[];   // [PK][PK_S]
-    constexpr int SUB = WT / PK;                 // sub-blocks per tile edge (4)
-    const int ib = blockIdx.y / SUB, rc = blockIdx.y % SUB;
-    const int kb = blockIdx.x / SUB, kc = blockIdx.x % SUB;
+    extern __shared__ __attribute__((aligned(16))) double tile[];   // [PKR][PK_S]
+    constexpr int SUBR = WT / PKR, SUBC = WT / PKC;                  // sub-blocks per tile edge (8 x 4)
+    const int ib = blockIdx.y / SUBR, g = blockIdx.y % SUBR;        // g: row group of the tile
+    const int kb = blockIdx.x / SUBC, kc = blockIdx.x % SUBC;
     if (kb > ib) return;
     const int t = threadIdx.x;
-    const int r0 = ib * WT + rc * PK, c0 = kb * WT + kc * PK;
-    for (int e = t; e < PK * PK; e += 256) {
-        const int r = e / PK, c = e % PK;
+    const int r0 = ib * WT + g * PKR, c0 = kb * WT + kc * PKC;
+    // thread -> row t>>2 ... (4 passes of 16 rows), 32 consecutive columns of that row in 16-byte loads
+    for (int e = t; e < PKR * PKC / 2; e += 256) {
+        const int r = e / (PKC / 2), c = (e % (PKC / 2)) * 2;
         const int gr = r0 + r, gc = c0 + c;
-        double v = 0.0;
-        if (gr < N && gc < N && gc <= gr) v = W[(size_t)gr * NP + gc];
-        tile[r * PK_S + c] = v;
+        d2 v{0.0, 0.0};
+        if (gr < N && gc <= gr) {                       // gc even: the pair (gc, gc+1) straddles the diagonal at most at gc+1
+            v = *reinterpret_cast<const d2*>(W + (size_t)gr * NP + gc);
+            if (gc + 1 > gr || gc + 1 >= N) v[1] = 0.0;
+            if (gc >= N) v[0] = 0.0;
+        }
+        tile[r * PK_S + c] = v[0];
+        tile[r * PK_S + c + 1] = v[1];
     }
     __syncthreads();
     d2* out = reinterpret_cast<d2*>(Wf + ((size_t)ib * (ib + 1) / 2 + kb) * WT_TILE_DOUBLES);
-    // this sub-block covers k4 in [32 kc, 32 kc + 32), row groups g in {2 rc, 2 rc + 1}
-    for (int e = t; e < (PK / 4) * 2 * 2 * 64; e += 256) {
-        const int lane = e & 63, q = (e >> 6) & 1, gl = (e >> 7) & 1, k4l = e >> 8;
+    // this sub-block covers k4 in [32 kc, 32 kc + 32) of row group g
+    for (int e = t; e < (PKC / 4) * 2 * 64; e += 256) {
+        const int lane = e & 63, q = (e >> 6) & 1, k4l = e >> 7;
         const int lc = lane & 15, lk = lane >> 4;
         const int col = 4 * k4l + lk;
-        const int rowb = 64 * gl + 16 * (2 * q) + lc;
+        const int rowb = 16 * (2 * q) + lc;
         const double v0 = tile[rowb * PK_S + col];
         const double v1 = tile[(rowb + 16) * PK_S + col];
-        const int k4 = (PK / 4) * kc + k4l, g = 2 * rc + gl;
+        const int k4 = (PKC / 4) * kc + k4l;
         out[((size_t)(k4 * WT_GROUPS + g) * 2 + q) * 64 + lane] = d2{v0, v1};
     }
 }
 
 void launch_pack_w(hipStream_t s, const double* W, int N, int NP, double* Wf) {
-    const int nb = NP / WT * (WT / PK);
-    const size_t lds = (size_t)PK * PK_S * sizeof(double);
+    const int nbt = NP / WT;
+    const size_t lds = (size_t)PKR * PK_S * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_pack_w), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_pack_w, dim3(nb, nb), dim3(256), lds, s, W, N, NP, Wf);
+    hipLaunchKernelGGL(k_pack_w, dim3(nbt * (WT / PKC), nbt * (WT / PKR)), dim3(256), lds, s, W, N, NP, Wf);
     hipMemsetAsync(Wf + (wf_doubles(NP) - WT_STEP_DOUBLES), 0, WT_STEP_DOUBLES * sizeof(double), s);
 }
 
