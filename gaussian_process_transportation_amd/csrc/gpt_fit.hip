@@ -16,7 +16,7 @@ namespace gpt {
 // =====================================================================================
 // Gram assembly: K[i][j] = c * exp(-0.5 |xs_i - xs_j|^2) (+ diag_add on the diagonal) for the
 // block lower triangle; padded rows/cols get the identity so the factorisation stays PD.
-// HBM-write bound: one 64x64 tile per workgroup, 16 consecutive doubles per thread.
+// HBM-write bound: one 64x64 tile per workgroup, 16 bytes per lane and store, 8 stores per thread.
 // =====================================================================================
 __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ Xs, int N, int NP, int ktype, double c,
                                               double diag_add, double* __restrict__ K) {
@@ -32,24 +32,25 @@ __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ Xs, int
         xj[t - 64][0] = p[0]; xj[t - 64][1] = p[1]; xj[t - 64][2] = p[2];
     }
     __syncthreads();
-    const int r = t >> 2, cs = (t & 3) * 16;
-    const int i = bi * 64 + r;
-    const double a0 = xi[r][0], a1 = xi[r][1], a2 = xi[r][2];
-    double* out = K + (size_t)i * NP + bj * 64 + cs;
+    // lane -> column pair, 2 rows per wave-level store: every store instruction writes two contiguous 512-B row segments
+    const int cc = (t & 31) * 2;
+    const double b0[2] = {xj[cc][0], xj[cc + 1][0]}, b1[2] = {xj[cc][1], xj[cc + 1][1]}, b2[2] = {xj[cc][2], xj[cc + 1][2]};
 #pragma unroll
-    for (int u = 0; u < 16; u += 2) {
+    for (int u = 0; u < 8; ++u) {
+        const int r = (t >> 5) + 8 * u;
+        const int i = bi * 64 + r;
+        const double a0 = xi[r][0], a1 = xi[r][1], a2 = xi[r][2];
         double v[2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            const int cc = cs + u + e;
-            const int j = bj * 64 + cc;
-            const double d0 = a0 - xj[cc][0], d1 = a1 - xj[cc][1], d2 = a2 - xj[cc][2];
+            const int j = bj * 64 + cc + e;
+            const double d0 = a0 - b0[e], d1 = a1 - b1[e], d2 = a2 - b2[e];
             double val = kernel_libm(ktype, c, d0 * d0 + d1 * d1 + d2 * d2);
             if (i == j) val = c + diag_add;            // k(0) = 1 exactly (kernels.py:1562)
             if (i >= N || j >= N) val = (i == j) ? 1.0 : 0.0;
             v[e] = val;
         }
-        *reinterpret_cast<d2*>(out + u) = d2{v[0], v[1]};
+        *reinterpret_cast<d2*>(K + (size_t)i * NP + bj * 64 + cc) = d2{v[0], v[1]};
     }
 }
 
