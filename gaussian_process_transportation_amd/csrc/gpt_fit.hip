@@ -698,20 +698,36 @@ void launch_potrf(hipStream_t s, double* K, double* W, int NP, int* info) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_finish), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fin_lds);
         attr_set = true;
     }
-    for (int p0 = 0; p0 < nb; p0 += ob) {
-        const int pend = p0 + ob < nb ? p0 + ob : nb;
-        for (int kb = p0; kb < pend; ++kb)
-            hipLaunchKernelGGL(k_potrf_step, dim3(nb - kb), dim3(256), step_lds, s, K, W, NP, kb, p0, info GPT_TRACE_NULL);
-        const int r0 = pend * NB, kw = (pend - p0) * NB;
-        const int rem = NP - r0;
-        if (rem <= 0) break;
-        GemmArgs c{};                                   // trailing update A22 -= L21 L21^T with the whole panel (K = kw)
-        c.A = K + (size_t)r0 * NP + (size_t)p0 * NB; c.lda = NP;
+    // Third level: panels are grouped by `grp`.  Inside a group a panel's own columns receive the group's earlier panels
+    // just before its steps (a thin GEMM, K = up to (grp-1) panels); everything behind the group is updated once per
+    // group with K = grp panels — the read-modify-write of the trailing matrix, which bounds the rank-128 update
+    // (42 TFLOP/s against 50-55 at rank 256-512), happens grp times less often.
+    // (measured: groups of 2 take 3 % off the Cholesky at N = 8192 and add 3-5 % at N <= 2500, where the extra thin GEMM
+    // on the chain costs more than the trailing matrix's traffic; tools/gpu_fit_ab.sh with GPT_POTRF_GROUP)
+    static int grp_env = -1;
+    if (grp_env < 0) { grp_env = 0; if (const char* e = getenv("GPT_POTRF_GROUP")) { const int v = atoi(e); if (v >= 1 && v <= 8) grp_env = v; } }
+    const int grp = grp_env ? grp_env : (NP >= 4096 ? 2 : 1);
+    auto syrk = [&](int row0, int ncols, int kcol0, int kw) {      // A[row0.., row0..row0+ncols) -= P P^T, P = A[row0.., kcol0..kcol0+kw)
+        const int rem = NP - row0;
+        if (rem <= 0 || kw <= 0) return;
+        GemmArgs c{};
+        c.A = K + (size_t)row0 * NP + kcol0; c.lda = NP;
         c.B = c.A; c.ldb = NP;
-        c.C = K + (size_t)r0 * NP + r0; c.ldc = NP;
-        c.M = c.M_last = rem; c.N = rem; c.K = c.K_last = kw; c.nbatch = 1;
+        c.C = K + (size_t)row0 * NP + row0; c.ldc = NP;
+        c.M = c.M_last = rem; c.N = ncols < rem ? ncols : rem; c.K = c.K_last = kw; c.nbatch = 1;
         c.alpha = -1.0; c.beta = 1.0; c.lower_only = 1;
         launch_gemm<true>(s, c);
+    };
+    const int gw = grp * ob;                                        // blocks per group
+    for (int g0 = 0; g0 < nb; g0 += gw) {
+        const int gend = g0 + gw < nb ? g0 + gw : nb;
+        for (int p0 = g0; p0 < gend; p0 += ob) {
+            const int pend = p0 + ob < gend ? p0 + ob : gend;
+            if (p0 > g0) syrk(p0 * NB, (pend - p0) * NB, g0 * NB, (p0 - g0) * NB);   // this panel's columns <- earlier panels of the group
+            for (int kb = p0; kb < pend; ++kb)
+                hipLaunchKernelGGL(k_potrf_step, dim3(nb - kb), dim3(256), step_lds, s, K, W, NP, kb, p0, info GPT_TRACE_NULL);
+        }
+        syrk(gend * NB, NP - gend * NB, g0 * NB, (gend - g0) * NB);                  // everything behind the group
     }
     hipLaunchKernelGGL(k_potrf_finish, dim3(nb), dim3(256), fin_lds, s, K, W, NP);
 }
