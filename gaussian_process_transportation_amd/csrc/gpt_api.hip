@@ -30,7 +30,7 @@ int fail(int code, const std::string& msg) {
 
 constexpr double MAGIC = 1196446769.0;   // "GPT1"
 constexpr int HDR_DOUBLES = 64;
-constexpr int64_t HOST_CHUNK = 1 << 18;  // queries per pass of the host-pointer API
+constexpr int64_t HOST_CHUNK = 1 << 17;  // queries per chunk of the host-pointer API (two chunks in flight)
 
 struct Layout {
     int64_t N, NP;
@@ -70,9 +70,12 @@ struct gpt_handle {
     bool have_factor_ws = false;   // dK/dW hold L / L^-1 of the current model
     std::vector<double> hostY;     // filtered targets (N,O) for the LML
     // staging of the host-pointer API
-    double *sq = nullptr, *smean = nullptr, *svar = nullptr, *sJ = nullptr, *sJvar = nullptr, *sdvar = nullptr;
+    // (two sets: while the results of one chunk travel to the host on `copy_stream`, the next chunk computes)
+    struct Staging { double *q = nullptr, *mean = nullptr, *var = nullptr, *J = nullptr, *Jvar = nullptr, *dvar = nullptr; } st[2];
     int64_t scap = 0;
     int sD = 0, sO = 0;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_done[2] = {}, ev_copied[2] = {};   // chunk computed / chunk's outputs copied out, per staging set
     double fit_ms[6] = {0, 0, 0, 0, 0, 0};
     hipEvent_t ev[7] = {};
     // per-kernel timing of the last predict (gpt_set_profiling)
@@ -96,8 +99,10 @@ int set_device(gpt_handle* h) {
 }
 
 void free_staging(gpt_handle* h) {
-    double** ptrs[] = {&h->sq, &h->smean, &h->svar, &h->sJ, &h->sJvar, &h->sdvar};
-    for (auto pp : ptrs) { if (*pp) (void)hipFree(*pp); *pp = nullptr; }
+    for (auto& t : h->st) {
+        double** ptrs[] = {&t.q, &t.mean, &t.var, &t.J, &t.Jvar, &t.dvar};
+        for (auto pp : ptrs) { if (*pp) (void)hipFree(*pp); *pp = nullptr; }
+    }
     h->scap = 0;
 }
 
@@ -136,13 +141,24 @@ int ensure_workspace(gpt_handle* h, int64_t NP, int npass) {
 
 int ensure_staging(gpt_handle* h, int64_t cap, int D, int O) {
     if (h->scap >= cap && h->sD == D && h->sO == O) return GPT_OK;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->copy_stream) HIPCHK(hipStreamSynchronize(h->copy_stream));
     free_staging(h);
-    HIPCHK(hipMalloc(&h->sq, (size_t)cap * D * sizeof(double)));
-    HIPCHK(hipMalloc(&h->smean, (size_t)cap * O * sizeof(double)));
-    HIPCHK(hipMalloc(&h->svar, (size_t)cap * sizeof(double)));
-    HIPCHK(hipMalloc(&h->sJ, (size_t)cap * O * D * sizeof(double)));
-    HIPCHK(hipMalloc(&h->sJvar, (size_t)cap * D * sizeof(double)));
-    HIPCHK(hipMalloc(&h->sdvar, (size_t)cap * D * sizeof(double)));
+    for (auto& t : h->st) {
+        HIPCHK(hipMalloc(&t.q, (size_t)cap * D * sizeof(double)));
+        HIPCHK(hipMalloc(&t.mean, (size_t)cap * O * sizeof(double)));
+        HIPCHK(hipMalloc(&t.var, (size_t)cap * sizeof(double)));
+        HIPCHK(hipMalloc(&t.J, (size_t)cap * O * D * sizeof(double)));
+        HIPCHK(hipMalloc(&t.Jvar, (size_t)cap * D * sizeof(double)));
+        HIPCHK(hipMalloc(&t.dvar, (size_t)cap * D * sizeof(double)));
+    }
+    if (!h->copy_stream) {
+        HIPCHK(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            HIPCHK(hipEventCreateWithFlags(&h->ev_done[i], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&h->ev_copied[i], hipEventDisableTiming));
+        }
+    }
     h->scap = cap; h->sD = D; h->sO = O;
     return GPT_OK;
 }
@@ -200,6 +216,7 @@ void gpt_destroy(gpt_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
+    if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
     free_staging(h);
     free_workspace(h);
     if (h->blob) (void)hipFree(h->blob);
@@ -207,6 +224,9 @@ void gpt_destroy(gpt_handle* h) {
     if (h->bscratch) (void)hipFree(h->bscratch);
     for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : h->pev) if (ev) (void)hipEventDestroy(ev);
+    for (auto& ev : h->ev_done) if (ev) (void)hipEventDestroy(ev);
+    for (auto& ev : h->ev_copied) if (ev) (void)hipEventDestroy(ev);
+    if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
 }
@@ -383,23 +403,44 @@ int gpt_predict_all(gpt_handle* h, const double* Xq, int64_t M, double* mean, do
     const int D = h->p.D, O = h->p.O;
     const int64_t cap = M < HOST_CHUNK ? M : HOST_CHUNK;
     if (int rc = ensure_staging(h, cap, D, O)) return rc;
-    hipStream_t s = h->stream;
-    for (int64_t off = 0; off < M; off += cap) {
-        const int64_t m = (M - off) < cap ? (M - off) : cap;
-        HIPCHK(hipMemcpyAsync(h->sq, Xq + off * D, (size_t)m * D * sizeof(double), hipMemcpyHostToDevice, s));
-        int rc = gpt_predict_all_dev(h, h->sq, m, mean ? h->smean : nullptr, var ? h->svar : nullptr,
-                                     J ? h->sJ : nullptr, Jvar ? h->sJvar : nullptr, dvar ? h->sdvar : nullptr);
-        if (rc) return rc;
-        if (mean) HIPCHK(hipMemcpyAsync(mean + off * O, h->smean, (size_t)m * O * sizeof(double), hipMemcpyDeviceToHost, s));
-        if (var) HIPCHK(hipMemcpyAsync(var + off, h->svar, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, s));
-        if (J) HIPCHK(hipMemcpyAsync(J + off * O * D, h->sJ, (size_t)m * O * D * sizeof(double), hipMemcpyDeviceToHost, s));
-        if (Jvar) HIPCHK(hipMemcpyAsync(Jvar + off * D, h->sJvar, (size_t)m * D * sizeof(double), hipMemcpyDeviceToHost, s));
+    hipStream_t s = h->stream, cs = h->copy_stream;
+    const int64_t nchunks = (M + cap - 1) / cap;
+    // chunk i computes on `s` in staging set i & 1; its outputs leave on `cs` while chunk i + 1 computes
+    auto enqueue = [&](int64_t i) -> int {
+        const int b = (int)(i & 1);
+        const int64_t off = i * cap, m = (M - off) < cap ? (M - off) : cap;
+        gpt_handle::Staging& t = h->st[b];
+        if (i >= 2) HIPCHK(hipStreamWaitEvent(s, h->ev_copied[b], 0));          // set b is free again
+        HIPCHK(hipMemcpyAsync(t.q, Xq + off * D, (size_t)m * D * sizeof(double), hipMemcpyHostToDevice, s));
+        if (int rc = gpt_predict_all_dev(h, t.q, m, mean ? t.mean : nullptr, var ? t.var : nullptr, J ? t.J : nullptr,
+                                         Jvar ? t.Jvar : nullptr, dvar ? t.dvar : nullptr))
+            return rc;
+        HIPCHK(hipEventRecord(h->ev_done[b], s));
+        return GPT_OK;
+    };
+    auto copy_out = [&](int64_t i) -> int {
+        const int b = (int)(i & 1);
+        const int64_t off = i * cap, m = (M - off) < cap ? (M - off) : cap;
+        const gpt_handle::Staging& t = h->st[b];
+        HIPCHK(hipStreamWaitEvent(cs, h->ev_done[b], 0));
+        if (mean) HIPCHK(hipMemcpyAsync(mean + off * O, t.mean, (size_t)m * O * sizeof(double), hipMemcpyDeviceToHost, cs));
+        if (var) HIPCHK(hipMemcpyAsync(var + off, t.var, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, cs));
+        if (J) HIPCHK(hipMemcpyAsync(J + off * O * D, t.J, (size_t)m * O * D * sizeof(double), hipMemcpyDeviceToHost, cs));
+        if (Jvar) HIPCHK(hipMemcpyAsync(Jvar + off * D, t.Jvar, (size_t)m * D * sizeof(double), hipMemcpyDeviceToHost, cs));
         if (dvar)
             for (int d = 0; d < D; ++d)   // device chunk is (D, m); host result is (D, M)
-                HIPCHK(hipMemcpyAsync(dvar + (size_t)d * M + off, h->sdvar + (size_t)d * m, (size_t)m * sizeof(double),
-                                      hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
+                HIPCHK(hipMemcpyAsync(dvar + (size_t)d * M + off, t.dvar + (size_t)d * m, (size_t)m * sizeof(double),
+                                      hipMemcpyDeviceToHost, cs));
+        HIPCHK(hipEventRecord(h->ev_copied[b], cs));
+        return GPT_OK;
+    };
+    if (int rc = enqueue(0)) return rc;
+    for (int64_t i = 0; i < nchunks; ++i) {
+        if (i + 1 < nchunks) { if (int rc = enqueue(i + 1)) return rc; }   // queued before chunk i's (host-blocking) copies
+        if (int rc = copy_out(i)) return rc;
     }
+    HIPCHK(hipStreamSynchronize(cs));
+    HIPCHK(hipStreamSynchronize(s));
     return GPT_OK;
 }
 
