@@ -101,6 +101,7 @@ class GaussianProcess:
             Y = Y[:, None]
         self.X = X
         self.Y = Y
+        self._memo = None
         self.n_features = np.shape(X)[1]
         self.n_samples = np.shape(X)[0]          # pre-filter count, as the reference (:29)
         self.n_outputs = np.shape(Y)[1]
@@ -167,7 +168,7 @@ class GaussianProcess:
             if self.n_outputs == 1:
                 return mean[:, 0], cov
             return mean, np.repeat(cov[:, :, None], self.n_outputs, axis=2)
-        out = self._handle.predict_all(x, mean=True, var=bool(return_std))
+        out = self._memo_lookup(x) or self._handle.predict_all(x, mean=True, var=bool(return_std))
         mean = out["mean"]
         if self.n_outputs == 1:
             mean = mean[:, 0]                       # sklearn squeezes single-target output (_gpr.py:449-451)
@@ -194,7 +195,7 @@ class GaussianProcess:
         """(:63-102)  J (M,O,D) = d mean_o / d x_d; with return_var also its variance, tiled over outputs."""
         self._require_fit()
         self._require_rbf("derivative")
-        out = self._handle.predict_all(x, J=True, Jvar=bool(return_var))
+        out = self._memo_lookup(x) or self._handle.predict_all(x, J=True, Jvar=bool(return_var))
         if not return_var:
             return out["J"]
         Sigma = np.repeat(out["Jvar"][:, None, :], self.n_outputs, axis=1)
@@ -207,6 +208,26 @@ class GaussianProcess:
         return self._handle.predict_all(x, dvar=True)["dvar"]
 
     # ------------------------------------------------------------------ fused metric path
+    def prefetch_posterior(self, x):
+        """Everything predict(x, return_std=True) and derivative(x, return_var=True) return, computed in ONE pass over
+        the factor (the variance and the three Jacobian-variance columns share the 4-column kernel: 4 column passes
+        instead of 1 + 4) and kept for the next calls with the same x.  Used by
+        GaussianProcessTransportation.apply_transportation, which asks for both at the same positions."""
+        self._require_fit()
+        self._require_rbf("prefetch_posterior")
+        xk = np.array(x, dtype=np.float64, order="C", copy=True)
+        self._memo = (xk, self._handle.predict_all(xk, mean=True, var=True, J=True, Jvar=True))
+
+    def _memo_lookup(self, x):
+        memo = getattr(self, "_memo", None)
+        if memo is None:
+            return None
+        xk, out = memo
+        x = np.asarray(x)
+        if x.shape != xk.shape or not np.array_equal(x, xk):
+            return None
+        return out
+
     def posterior(self, x, jacobian_variance=False):
         """One call for mean (M,O), raw variance (M,), Jacobian (M,O,D) [and Jacobian variance (M,D)]."""
         self._require_fit()

@@ -43,8 +43,10 @@ class GaussianProcessTransportation:
         """Moves the demonstration; velocities and orientations follow when they were provided (:19-27)."""
         before = self._input("training_traj")
         self.training_traj_old = before
-        self.training_traj, self.std = self.method.transport(before)
         velocities = getattr(self, "training_delta", _MISSING)
+        if velocities is not _MISSING:
+            self.method.prefetch(before)              # std and Jacobian variance at the same positions: one pass
+        self.training_traj, self.std = self.method.transport(before)
         if velocities is not _MISSING:
             self.training_delta, self.var_vel_transported = self.method.transport_velocity(before, velocities)
         orientations = getattr(self, "training_ori", _MISSING)

@@ -18,6 +18,17 @@ class PolicyTransportation:
         self.delta_distribution = np.asarray(target_distribution, dtype=np.float64) - source_aligned
         self.delta_map.fit(source_aligned, self.delta_distribution)
 
+    def prefetch(self, pos):
+        """Optional: lets a delta_map that can (GaussianProcess.prefetch_posterior) compute what transport(pos) and
+        transport_velocity(pos, .) will ask for in one pass.  No effect on results."""
+        hook = getattr(self.delta_map, "prefetch_posterior", None)
+        if hook is None:
+            return
+        try:
+            hook(self.affine_transform.predict(pos))
+        except NotImplementedError:            # e.g. a Matern delta_map: the calls that follow decide what fails
+            pass
+
     def transport(self, pos, return_std=True):
         """Returns (transported positions, std).  The reference raises NameError for
         return_std=False (its :35 returns an unbound name); here std is None in that case."""

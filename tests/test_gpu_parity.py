@@ -635,3 +635,25 @@ def test_surface_3d_example_end_to_end():
     assert_parity(out["theta"], g["theta_fit"], 1e-3, "fitted theta")
     assert_parity(out["X1"], g["traj"], 1e-4, "transported demo")
     assert_parity(out["deltaX1"], g["vel"], 1e-3, "transported velocities")
+
+
+def test_prefetch_changes_nothing_but_the_number_of_passes():
+    """apply_transportation() asks for std and Jacobian variance at the same positions; the one-pass prefetch must give
+    what the two separate calls give (variance from the 4-column instead of the 1-column kernel: last-bit level)."""
+    from sklearn.gaussian_process.kernels import RBF, WhiteKernel, ConstantKernel as C
+    from gaussian_process_transportation_amd import GaussianProcess
+    rng = np.random.default_rng(4)
+    X = rng.uniform(0, 1, (300, 3)); Y = 0.1 * np.sin(3 * X)
+    Xq = rng.uniform(0, 1, (1000, 3))
+    gp = GaussianProcess(kernel=C(0.5) * RBF([0.3, 0.2, 0.25]) + WhiteKernel(1e-3), optimizer=None, verbose=False).fit(X, Y)
+    m0, s0 = gp.predict(Xq, return_std=True)
+    J0, V0 = gp.derivative(Xq, return_var=True)
+    gp.prefetch_posterior(Xq)
+    m1, s1 = gp.predict(Xq, return_std=True)
+    J1, V1 = gp.derivative(Xq, return_var=True)
+    assert np.array_equal(m0, m1) and np.array_equal(J0, J1) and np.array_equal(V0, V1)
+    assert_parity(s1, s0, 1e-10, "std from the 4-column pass")
+    other = gp.predict(Xq[:10], return_std=True)[0]            # different x: not served from the memo
+    assert other.shape == (10, 3) and np.array_equal(other, m0[:10])
+    gp.fit(X, 2 * Y)                                           # a new fit drops the memo
+    assert not np.array_equal(gp.predict(Xq), m0)
