@@ -98,7 +98,8 @@ int gpt_derivative(gpt_handle* h, const double* Xq, int64_t M, double* J, double
 int gpt_dvariance(gpt_handle* h, const double* Xq, int64_t M, double* g);
 
 /* Fused metric path: any of mean (M,O) / var (M,) / J (M,O,D) / Jvar (M,D) / dvar (D,M) may be
- * NULL.  Host memory; queries are streamed through the device in chunks. */
+ * NULL.  Host memory (pageable is fine); queries are streamed through the device in chunks of 131072, the outputs of
+ * one chunk leaving on a copy stream while the next chunk computes.  Returns when every output is in place. */
 int gpt_predict_all(gpt_handle* h, const double* Xq, int64_t M, double* mean, double* var,
                     double* J, double* Jvar, double* dvar);
 /* Same with every pointer in device memory; asynchronous on the handle's stream. */
