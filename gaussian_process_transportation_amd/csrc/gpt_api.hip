@@ -348,6 +348,38 @@ static int fit_impl(gpt_handle* h, const double* X, const double* Y, int64_t N, 
     return GPT_OK;
 }
 
+namespace {
+// grow-only scratch of the variance kernel; reallocation waits for work that may still use the old buffers
+int ensure_var_scratch(gpt_handle* h, int64_t M, int ncomp) {
+    hipStream_t s = h->stream;
+    const size_t need = var_slab_doubles(M, ncomp);
+    if (need > h->slab_cap) {
+        HIPCHK(hipStreamSynchronize(s));
+        if (h->slab) (void)hipFree(h->slab);
+        h->slab = nullptr; h->slab_cap = 0;
+        HIPCHK(hipMalloc(&h->slab, need * sizeof(double)));
+        h->slab_cap = need;
+    }
+    const size_t needb = var_bscratch_doubles(h->p.NP);
+    if (needb > h->bscratch_cap) {
+        HIPCHK(hipStreamSynchronize(s));
+        if (h->bscratch) (void)hipFree(h->bscratch);
+        h->bscratch = nullptr; h->bscratch_cap = 0;
+        HIPCHK(hipMalloc(&h->bscratch, needb * sizeof(double)));
+        h->bscratch_cap = needb;
+    }
+    return GPT_OK;
+}
+}  // namespace
+
+int gpt_reserve(gpt_handle* h, int64_t M, int jacobian_variance) {
+    if (!h) return fail(GPT_E_ARG, "gpt_reserve: NULL handle");
+    if (!h->committed) return fail(GPT_E_STATE, "gpt_reserve: model is not fitted");
+    if (M < 0) return fail(GPT_E_ARG, "gpt_reserve: bad query count");
+    if (int rc = set_device(h)) return rc;
+    return M == 0 ? GPT_OK : ensure_var_scratch(h, M, jacobian_variance ? 4 : 1);
+}
+
 int gpt_predict_all_dev(gpt_handle* h, const double* Xq, int64_t M, double* mean, double* var,
                         double* J, double* Jvar, double* dvar) {
     if (!h) return fail(GPT_E_ARG, "gpt_predict_all_dev: NULL handle");
@@ -368,22 +400,7 @@ int gpt_predict_all_dev(gpt_handle* h, const double* Xq, int64_t M, double* mean
     }
     if (h->pred_var) {
         const int ncomp = (Jvar || dvar) ? 4 : 1;
-        const size_t need = var_slab_doubles(M, ncomp);
-        if (need > h->slab_cap) {      // grow-only scratch; reallocation waits for work that may still use it
-            HIPCHK(hipStreamSynchronize(s));
-            if (h->slab) (void)hipFree(h->slab);
-            h->slab = nullptr; h->slab_cap = 0;
-            HIPCHK(hipMalloc(&h->slab, need * sizeof(double)));
-            h->slab_cap = need;
-        }
-        const size_t needb = var_bscratch_doubles(h->p.NP);
-        if (needb > h->bscratch_cap) {
-            HIPCHK(hipStreamSynchronize(s));
-            if (h->bscratch) (void)hipFree(h->bscratch);
-            h->bscratch = nullptr; h->bscratch_cap = 0;
-            HIPCHK(hipMalloc(&h->bscratch, needb * sizeof(double)));
-            h->bscratch_cap = needb;
-        }
+        if (int rc = ensure_var_scratch(h, M, ncomp)) return rc;
         if (prof) HIPCHK(hipEventRecord(h->pev[2], s));
         if (ncomp == 4) launch_var(s, h->p, h->dXs(), h->dWf(), Xq, M, 4, var, Jvar, dvar, h->slab, h->bscratch);
         else launch_var(s, h->p, h->dXs(), h->dWf(), Xq, M, 1, var, nullptr, nullptr, h->slab, h->bscratch);

@@ -105,6 +105,9 @@ int gpt_predict_all(gpt_handle* h, const double* Xq, int64_t M, double* mean, do
 /* Same with every pointer in device memory; asynchronous on the handle's stream. */
 int gpt_predict_all_dev(gpt_handle* h, const double* Xq_dev, int64_t M, double* mean_dev,
                         double* var_dev, double* J_dev, double* Jvar_dev, double* dvar_dev);
+/* (new) Allocates the library-owned scratch a gpt_predict_all_dev call with M queries will use (grow-only; with
+ * jacobian_variance != 0 for the 4-column path), so that the first such call does not allocate. */
+int gpt_reserve(gpt_handle* h, int64_t M, int jacobian_variance);
 
 /* predict(return_cov=True) — replaces sklearn/_gpr.py:458-470: mean (M,O) (may be NULL) and the joint
  * posterior covariance cov (M,M) = k(Xq,Xq) + noise_level*I - V^T V, V = L^-1 K*^T (identical for every
