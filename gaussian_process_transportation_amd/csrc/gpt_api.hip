@@ -399,11 +399,11 @@ int gpt_predict_all_dev(gpt_handle* h, const double* Xq, int64_t M, double* mean
         if (prof) HIPCHK(hipEventRecord(h->pev[1], s));
     }
     if (h->pred_var) {
-        const int ncomp = (Jvar || dvar) ? 4 : 1;
+        const int ncomp = dvar ? 4 : (Jvar ? (var ? 4 : 3) : 1);     // 3: Jacobian variance alone (no k* column)
         if (int rc = ensure_var_scratch(h, M, ncomp)) return rc;
         if (prof) HIPCHK(hipEventRecord(h->pev[2], s));
-        if (ncomp == 4) launch_var(s, h->p, h->dXs(), h->dWf(), Xq, M, 4, var, Jvar, dvar, h->slab, h->bscratch);
-        else launch_var(s, h->p, h->dXs(), h->dWf(), Xq, M, 1, var, nullptr, nullptr, h->slab, h->bscratch);
+        if (ncomp == 1) launch_var(s, h->p, h->dXs(), h->dWf(), Xq, M, 1, var, nullptr, nullptr, h->slab, h->bscratch);
+        else launch_var(s, h->p, h->dXs(), h->dWf(), Xq, M, ncomp, var, Jvar, dvar, h->slab, h->bscratch);
         if (prof) HIPCHK(hipEventRecord(h->pev[3], s));
     }
     HIPCHK(hipGetLastError());

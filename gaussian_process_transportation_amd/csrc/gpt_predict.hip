@@ -165,6 +165,7 @@ void launch_mean_jac(hipStream_t s, const KernelParams& p, const double* Xs, con
 // 8-step chunks (-3.7 %), barrier-free sweeps with every wave reading B from the scratch image (-3 %: L2
 // hit rate 97 % -> 56 %, 3.4 TB/s from beyond L2, clock 2.18 GHz), deeper A prefetch (0 %).
 // NCOMP = 1: one column per query (k*).  NCOMP = 4: four columns per query (k*, dk_0, dk_1, dk_2).
+// NCOMP = 3: three columns per query (dk_0, dk_1, dk_2) — the Jacobian variance without the variance.
 // ------------------------------------------------------------------------------------------
 // Timing-only ablation builds (results are wrong unless 0): -DGPT_ABL=1 no per-chunk barrier, 2 no A-operand
 // loads, 3 diagonal tile skipped, 4 no B fill (LDS image left as is), 5 no MFMAs.  tools/gpu_ablate.sh,
@@ -242,7 +243,10 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlan pl, cons
     const int64_t rounds = pl.nfull / pl.P;
 
     constexpr double RS2 = 0.70710678118654752440;    // coordinates are pre-scaled by 1/sqrt(2): t = ln c - |d'|^2
-    const int comp = (NCOMP == 1) ? 0 : (lc & 3);     // NCOMP=4: b = kv * (cb + sum_d cd[d] * d'_d)
+    // NCOMP=4: column = 4 query + comp, comp = lc & 3 in every tile: b = kv * (cbv + sum_d cd[d] * d'_d).
+    // NCOMP=3 (Jacobian variance alone, no k* column): column = 3 query + d; the d of a lane's column changes from tile
+    // to tile and from block to block (64 = 1 mod 3): d = (cb + t + lc) mod 3, selected in `produce`.
+    const int comp = (NCOMP == 4) ? (lc & 3) : 0;
     const double cbv = (comp == 0) ? 1.0 : 0.0;
     double cd[3];
 #pragma unroll
@@ -276,6 +280,9 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlan pl, cons
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 
         double ssq[4] = {0.0, 0.0, 0.0, 0.0}, crs[4] = {0.0, 0.0, 0.0, 0.0};
+        const int base3 = (NCOMP == 3) ? (int)((cb + lc) % 3) : 0;
+        const double sc3[3] = {p.inv_ls[0] * 1.41421356237309504880, p.inv_ls[1] * 1.41421356237309504880,
+                               p.inv_ls[2] * 1.41421356237309504880};
 
         // One sweep of i-block ib.  GEN = true (first sweep of the block): B fragments are generated and a copy
         // is kept in the scratch image; GEN = false: they are reloaded from it.  Two instantiations, so that the
@@ -288,7 +295,7 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlan pl, cons
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const int64_t col = cb * VAR_COLS + 16 * t + lc;
-                    const int64_t m = (NCOMP == 1) ? col : (col >> 2);
+                    const int64_t m = (NCOMP == 1) ? col : ((NCOMP == 4) ? (col >> 2) : (col / 3));
                     const int64_t mm = (m < M) ? m : (M - 1);
 #pragma unroll
                     for (int d = 0; d < 3; ++d) q[t][d] = (d < D) ? Xq[mm * D + d] * (p.inv_ls[d] * RS2) : 0.0;
@@ -317,7 +324,13 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlan pl, cons
                         hh = fma(d1, d1, hh);
                         hh = fma(d2_, d2_, hh);
                         const double kv = kernel_tab<KT>(hh, lnc, Tt);
-                        b[t] = (NCOMP == 1) ? kv : kv * (cbv + cd[0] * d0 + cd[1] * d1 + cd[2] * d2_);
+                        if (NCOMP == 3) {
+                            const int dsel = (base3 + t) % 3;                 // base3 = (cb + lc) mod 3
+                            const double e = (dsel == 0) ? d0 * sc3[0] : ((dsel == 1) ? d1 * sc3[1] : d2_ * sc3[2]);
+                            b[t] = kv * e;
+                        } else {
+                            b[t] = (NCOMP == 1) ? kv : kv * (cbv + cd[0] * d0 + cd[1] * d1 + cd[2] * d2_);
+                        }
                     }
                     *reinterpret_cast<d4*>(dstl) = b;
                     d2* dst = buni + (size_t)k4 * 128 + blane;
@@ -520,8 +533,8 @@ __global__ __launch_bounds__(64) void k_var_finalize(KernelParams p, VarPlan pl,
     }
     const int D = p.D;
     const int64_t col = cb * VAR_COLS + cl;
-    const int64_t m = (NCOMP == 1) ? col : (col >> 2);
-    const int cmp = (NCOMP == 1) ? 0 : (int)(col & 3);
+    const int64_t m = (NCOMP == 1) ? col : ((NCOMP == 4) ? (col >> 2) : (col / 3));
+    const int cmp = (NCOMP == 1) ? 0 : ((NCOMP == 4) ? (int)(col & 3) : 1 + (int)(col % 3));
     if (m >= M) return;
     if (cmp == 0) {
         if (var) { const double v = p.c + p.noise - s2; var[m] = v < 0.0 ? 0.0 : v; }
@@ -574,7 +587,8 @@ void launch_var(hipStream_t s, const KernelParams& p, const double* Xs, const do
     static bool attr_set = false;
     if (!attr_set) {      // 128 KiB of dynamic LDS per workgroup
         const void* fns[] = {reinterpret_cast<const void*>(k_var<1, false, KT_RBF>), reinterpret_cast<const void*>(k_var<4, true, KT_RBF>),
-                             reinterpret_cast<const void*>(k_var<4, false, KT_RBF>), reinterpret_cast<const void*>(k_var<1, false, KT_MATERN12>),
+                             reinterpret_cast<const void*>(k_var<4, false, KT_RBF>), reinterpret_cast<const void*>(k_var<3, false, KT_RBF>),
+                             reinterpret_cast<const void*>(k_var<1, false, KT_MATERN12>),
                              reinterpret_cast<const void*>(k_var<1, false, KT_MATERN32>), reinterpret_cast<const void*>(k_var<1, false, KT_MATERN52>)};
         for (const void* f : fns) hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VAR_LDS_BYTES);
         attr_set = true;
@@ -588,6 +602,9 @@ void launch_var(hipStream_t s, const KernelParams& p, const double* Xs, const do
             default: hipLaunchKernelGGL((k_var<1, false, KT_RBF>), grid, dim3(512), VAR_LDS_BYTES, s, p, pl, Xs, Wf, Xq, M, slab, bscratch);
         }
         hipLaunchKernelGGL((k_var_finalize<1>), fgrid, dim3(64), 0, s, p, pl, slab, M, var, Jvar, dvar);
+    } else if (ncomp == 3) {      // Jacobian variance alone: three columns per query
+        hipLaunchKernelGGL((k_var<3, false, KT_RBF>), grid, dim3(512), VAR_LDS_BYTES, s, p, pl, Xs, Wf, Xq, M, slab, bscratch);
+        hipLaunchKernelGGL((k_var_finalize<3>), fgrid, dim3(64), 0, s, p, pl, slab, M, var, Jvar, dvar);
     } else {      // Jacobian variance / d var: RBF only (the API refuses other kernels)
         if (dvar) hipLaunchKernelGGL((k_var<4, true, KT_RBF>), grid, dim3(512), VAR_LDS_BYTES, s, p, pl, Xs, Wf, Xq, M, slab, bscratch);
         else hipLaunchKernelGGL((k_var<4, false, KT_RBF>), grid, dim3(512), VAR_LDS_BYTES, s, p, pl, Xs, Wf, Xq, M, slab, bscratch);
