@@ -658,3 +658,26 @@ def test_prefetch_changes_nothing_but_the_number_of_passes():
     assert other.shape == (10, 3) and np.array_equal(other, m0[:10])
     gp.fit(X, 2 * Y)                                           # a new fit drops the memo
     assert not np.array_equal(gp.predict(Xq), m0)
+
+
+@pytest.mark.parametrize("D", [1, 2, 3])
+def test_jacobian_variance_alone_matches_the_four_column_path(D):
+    """gpt_predict_all with Jvar but without var / dvar takes the 3-columns-per-query kernel (k_var<3>); with var it takes
+    the 4-column one.  Same numbers to the last bits, for every input dimension (unused components are zero columns),
+    and for a query count that leaves the last column block ragged."""
+    from gaussian_process_transportation_amd import _lib
+    from oracle import gp_oracle as orc
+    rng = np.random.default_rng(10 + D)
+    X = rng.uniform(0, 1, (700, D)); Y = np.sin(3 * X[:, :1])
+    Xq = rng.uniform(-0.1, 1.1, (1237, D))
+    ls = np.array([0.3, 0.2, 0.25][:D])
+    h = _lib.Handle(0)
+    h.fit(X, Y, ls, 0.8, 1e-3, 1e-10)
+    alone = h.predict_all(Xq, J=True, Jvar=True)
+    full = h.predict_all(Xq, var=True, J=True, Jvar=True)
+    assert alone["Jvar"].shape == (1237, D) and np.array_equal(alone["J"], full["J"])
+    assert_parity(alone["Jvar"], full["Jvar"], 1e-10, "Jvar 3-column vs 4-column")
+    o = orc.GaussianProcessOracle(0.8, ls, 1e-3, 1e-10).fit(X, Y)
+    _, Jv = o.derivative(Xq, return_var=True)
+    assert_parity(alone["Jvar"], Jv[:, 0, :], RTOL, "Jvar vs oracle")
+    h.close()
