@@ -165,7 +165,7 @@ void launch_mean_jac(hipStream_t s, const KernelParams& p, const double* Xs, con
 // 8-step chunks (-3.7 %), barrier-free sweeps with every wave reading B from the scratch image (-3 %: L2
 // hit rate 97 % -> 56 %, 3.4 TB/s from beyond L2, clock 2.18 GHz), deeper A prefetch (0 %).
 // NCOMP = 1: one column per query (k*).  NCOMP = 4: four columns per query (k*, dk_0, dk_1, dk_2).
-// NCOMP = 3: three columns per query (dk_0, dk_1, dk_2) — the Jacobian variance without the variance.
+// NCOMP = 3: D columns per query (dk_0 .. dk_{D-1}) — the Jacobian variance without the variance.
 // ------------------------------------------------------------------------------------------
 // Timing-only ablation builds (results are wrong unless 0): -DGPT_ABL=1 no per-chunk barrier, 2 no A-operand
 // loads, 3 diagonal tile skipped, 4 no B fill (LDS image left as is), 5 no MFMAs.  tools/gpu_ablate.sh,
@@ -244,8 +244,8 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlan pl, cons
 
     constexpr double RS2 = 0.70710678118654752440;    // coordinates are pre-scaled by 1/sqrt(2): t = ln c - |d'|^2
     // NCOMP=4: column = 4 query + comp, comp = lc & 3 in every tile: b = kv * (cbv + sum_d cd[d] * d'_d).
-    // NCOMP=3 (Jacobian variance alone, no k* column): column = 3 query + d; the d of a lane's column changes from tile
-    // to tile and from block to block (64 = 1 mod 3): d = (cb + t + lc) mod 3, selected in `produce`.
+    // NCOMP=3 (Jacobian variance alone, no k* column): column = D query + d, D columns per query; for D = 3 the d of a
+    // lane's column changes from tile to tile and from block to block (16 = 64 = 1 mod 3), selected in `produce`.
     const int comp = (NCOMP == 4) ? (lc & 3) : 0;
     const double cbv = (comp == 0) ? 1.0 : 0.0;
     double cd[3];
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlan pl, cons
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 
         double ssq[4] = {0.0, 0.0, 0.0, 0.0}, crs[4] = {0.0, 0.0, 0.0, 0.0};
-        const int base3 = (NCOMP == 3) ? (int)((cb + lc) % 3) : 0;
+        const int base3 = (NCOMP == 3) ? (int)((cb * VAR_COLS + lc) % D) : 0;
         const double sc3[3] = {p.inv_ls[0] * 1.41421356237309504880, p.inv_ls[1] * 1.41421356237309504880,
                                p.inv_ls[2] * 1.41421356237309504880};
 
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlan pl, cons
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const int64_t col = cb * VAR_COLS + 16 * t + lc;
-                    const int64_t m = (NCOMP == 1) ? col : ((NCOMP == 4) ? (col >> 2) : (col / 3));
+                    const int64_t m = (NCOMP == 1) ? col : ((NCOMP == 4) ? (col >> 2) : (col / D));
                     const int64_t mm = (m < M) ? m : (M - 1);
 #pragma unroll
                     for (int d = 0; d < 3; ++d) q[t][d] = (d < D) ? Xq[mm * D + d] * (p.inv_ls[d] * RS2) : 0.0;
@@ -325,7 +325,8 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlan pl, cons
                         hh = fma(d2_, d2_, hh);
                         const double kv = kernel_tab<KT>(hh, lnc, Tt);
                         if (NCOMP == 3) {
-                            const int dsel = (base3 + t) % 3;                 // base3 = (cb + lc) mod 3
+                            int dsel = base3 + ((D == 3) ? t : 0);            // (64 cb + 16 t + lc) mod D, base3 = (64 cb + lc) mod D
+                            dsel = (dsel >= D) ? dsel - D : dsel;
                             const double e = (dsel == 0) ? d0 * sc3[0] : ((dsel == 1) ? d1 * sc3[1] : d2_ * sc3[2]);
                             b[t] = kv * e;
                         } else {
@@ -533,8 +534,8 @@ __global__ __launch_bounds__(64) void k_var_finalize(KernelParams p, VarPlan pl,
     }
     const int D = p.D;
     const int64_t col = cb * VAR_COLS + cl;
-    const int64_t m = (NCOMP == 1) ? col : ((NCOMP == 4) ? (col >> 2) : (col / 3));
-    const int cmp = (NCOMP == 1) ? 0 : ((NCOMP == 4) ? (int)(col & 3) : 1 + (int)(col % 3));
+    const int64_t m = (NCOMP == 1) ? col : ((NCOMP == 4) ? (col >> 2) : (col / D));
+    const int cmp = (NCOMP == 1) ? 0 : ((NCOMP == 4) ? (int)(col & 3) : 1 + (int)(col % D));
     if (m >= M) return;
     if (cmp == 0) {
         if (var) { const double v = p.c + p.noise - s2; var[m] = v < 0.0 ? 0.0 : v; }
@@ -563,7 +564,8 @@ static int var_workgroups() {
 static VarPlan make_plan(const KernelParams& p, int64_t M, int ncomp) {
     VarPlan pl;
     pl.nbi = p.NP / WT;
-    pl.ncb = (M * ncomp + VAR_COLS - 1) / VAR_COLS;
+    const int cpq = (ncomp == 3) ? p.D : ncomp;          // ncomp 3 = Jacobian variance alone: D columns per query
+    pl.ncb = (M * cpq + VAR_COLS - 1) / VAR_COLS;
     pl.P = var_workgroups();
     pl.T = var_cost_prefix(pl.nbi);
     pl.nfull = pl.ncb / pl.P * pl.P;
