@@ -68,8 +68,13 @@ for it in range(cases):
         scale = float(np.max(c / (ls * span) ** 2))
         errs["Jvar"] = float(np.max(np.abs(out["Jvar"] - Jv[:, 0, :])) / scale)
         errs["dvar"] = float(np.max(np.abs(out["dvar"] - o.derivative_of_variance(Xq))) / (scale ** 0.5 * (c + noise) ** 0.5 * 2))
+    if want_der:                      # Jacobian variance alone: the D-columns-per-query kernel
+        alone = h.predict_all(Xq, J=True, Jvar=True)["Jvar"]
+        errs["Jvar_alone"] = float(np.max(np.abs(alone - Jv[:, 0, :])) / scale)
     for k, v in errs.items():
         worst[k] = max(worst.get(k, 0.0), v)
+    if (it + 1) % 10 == 0:
+        print(f"... {it + 1} cases", flush=True)
     if max(errs.values()) > 1e-6 or not all(np.isfinite(list(errs.values()))):
         bad += 1
         print("LARGE:", tag, {k: f"{v:.2e}" for k, v in errs.items()}, f"cond(K)~{np.linalg.cond(o.L_) ** 2:.2e}", flush=True)
