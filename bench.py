@@ -1,6 +1,6 @@
 """Benchmark of the GP-transportation hot path on MI355X.
 
-    python bench.py --gpus 1 --steps 5 --warmup 1
+    python bench.py --gpus N --steps K --warmup W          (N > 1: starts its own N ranks, see `launch_ranks`)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -23,6 +23,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_FP64_MFMA_TFLOPS = 78.6      # MI355X datasheet fp64 matrix peak (not in MI355X_MICROARCH.md)
+PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md "Peak FP32 (matrix)": v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD
 
 
 def flops_per_query(N, D, O, jvar):
@@ -82,6 +83,85 @@ def cpu_baseline(N, D, O, sample, jvar):
     return out
 
 
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no torch.distributed environment: this process becomes a pure
+    launcher.  It has not imported torch, loaded libgpt_hip.so or made any HIP call (and never does): it starts
+    one fresh child process per GPU with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, relays what the ranks
+    print (rank 0's JSON line on stdout, everything else on stderr) and exits with the worst return code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:                      # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GPT_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rcs = [None] * len(procs)
+    while any(rc is None for rc in rcs):
+        for r, pr in enumerate(procs):
+            if rcs[r] is None:
+                rcs[r] = pr.poll()
+        if any(rc not in (None, 0) for rc in rcs):   # a failed rank leaves the others inside a collective: stop them
+            for r, pr in enumerate(procs):
+                if rcs[r] is None:
+                    pr.terminate()                   # exactly the PIDs started above
+                    rcs[r] = pr.wait()
+            break
+        time.sleep(0.05)
+    reader.join(timeout=30)
+    out0 = "".join(c or "" for c in chunks)
+    lines = [ln for ln in (out0 or "").splitlines() if ln.strip()]
+    for ln in lines:
+        print(ln, flush=True)
+    worst = max((abs(rc) for rc in rcs), default=0)
+    if worst == 0 and not any(ln.lstrip().startswith("{") for ln in lines):
+        print("bench launcher: rank 0 printed no JSON line", file=sys.stderr)
+        worst = 1
+    return worst
+
+
+def dry_run(args):
+    """--dry-run: the multi-rank skeleton of the benchmark (rendezvous, barriers, rank count check, max-reduce of the
+    elapsed time, one JSON line from rank 0) over gloo on the CPU — no GPU, no library; what the CPU test of the
+    launcher runs."""
+    import datetime
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
+    if os.environ.get("GPT_BENCH_DRY_FAIL_RANK") == str(rank):      # test hook: this rank dies before the rendezvous
+        raise SystemExit(3)
+    dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=120))
+    ones = torch.ones(1, dtype=torch.float64)
+    dist.all_reduce(ones)
+    if int(ones.item()) != args.gpus or dist.get_world_size() != args.gpus:
+        raise SystemExit(f"dry run: {int(ones.item())} ranks answered, --gpus {args.gpus}")
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001 * (1 + rank))
+    dist.barrier()
+    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_seen": int(ones.item()), "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": float(tt.item()) / max(args.steps, 1) * 1e3,
+                          "backend": "gloo"}), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -91,21 +171,39 @@ def main():
     ap.add_argument("--queries", type=int, default=500_000, help="queries per GPU per step")
     ap.add_argument("--jvar", action="store_true", help="also compute the Jacobian variance (mode J+Jvar)")
     ap.add_argument("--cpu-sample", type=int, default=2000, help="queries of the CPU baseline (0 = skip)")
+    ap.add_argument("--config", choices=["exact", "svgp"], default="exact",
+                    help="exact: the headline metric (BASELINE configs[2]/[3]); svgp: configs[4], fp32 SVGP-MIMO path")
+    ap.add_argument("--inducing", type=int, default=2048, help="inducing points of --config svgp")
+    ap.add_argument("--dry-run", action="store_true", help="multi-rank skeleton over gloo on the CPU, no GPU work")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
 
+    # ---- launcher: before torch / the library / any HIP call
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, sys.argv[1:]))
+    if args.dry_run:
+        return dry_run(args)
+
+    if args.config == "svgp":
+        return run_svgp(args)
+    return run_exact(args)
+
+
+def init_ranks(args):
+    """torch + library + (for more than one rank, or GPT_BENCH_FORCE_DIST=1) the RCCL process group."""
     import torch
     from gaussian_process_transportation_amd import _lib
-    from gaussian_process_transportation_amd.distributed import broadcast_model
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     _lib.require_gpu()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
+    ranks_seen = 1
     # GPT_BENCH_FORCE_DIST=1 runs the multi-rank code path (RCCL init, model broadcast, barriers, max-reduce) with
     # however many ranks there are, also one: the rehearsal available on a one-GPU box
     use_dist = world > 1 or os.environ.get("GPT_BENCH_FORCE_DIST") == "1"
@@ -116,45 +214,32 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
-
-    N, D, O, M = args.n_source, 3, 3, args.queries
+        seen = torch.ones(1, dtype=torch.float64, device=dev)
+        dist.all_reduce(seen)                                  # every rank checks that RCCL sees --gpus ranks
+        ranks_seen = int(seen.item())
+        if ranks_seen != args.gpus or dist.get_world_size() != args.gpus:
+            raise SystemExit(f"rank {rank}: RCCL sees {ranks_seen} ranks (world size {dist.get_world_size()}), --gpus {args.gpus}")
     h = _lib.Handle(local_rank)
     h.set_stream(torch.cuda.current_stream().cuda_stream)
+    return torch, dist, h, rank, world, dev, use_dist, ranks_seen
 
-    # ---- fit on rank 0, broadcast the factor (outside the timed region; reported)
-    fit_ms = bcast_ms = None
-    fit_timings = None
-    if rank == 0:
-        X, Y = synthetic_sources(N, D)
-        ls = np.array([0.1] * D)
-        h.fit(X, Y, ls, 0.1, 1e-4, 1e-10)                  # first call: allocations + code load
-        t0 = time.perf_counter()
-        h.fit(X, Y, ls, 0.1, 1e-4, 1e-10)
-        fit_ms = (time.perf_counter() - t0) * 1e3
-        fit_timings = h.fit_timings()
-    bcast_bytes = 0
-    if use_dist:
-        dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        bcast_bytes = broadcast_model(h, fitted=(rank == 0), src=0, device=dev)
-        torch.cuda.synchronize()
-        bcast_ms = (time.perf_counter() - t0) * 1e3
 
-    # ---- this rank's query shard, resident in HBM
-    xq_host = np.random.default_rng(1 + rank).uniform(-0.1, 1.1, (M, D))
-    xq = torch.from_numpy(xq_host).to(dev)
-    mean = torch.empty((M, O), dtype=torch.float64, device=dev)
-    var = torch.empty((M,), dtype=torch.float64, device=dev)
-    J = torch.empty((M, O, D), dtype=torch.float64, device=dev)
-    Jvar = torch.empty((M, D), dtype=torch.float64, device=dev) if args.jvar else None
+def broadcast_fitted(torch, dist, h, rank, dev, use_dist):
+    """One RCCL broadcast of the model blob from rank 0 (outside the timed region: once per fit, not per batch)."""
+    from gaussian_process_transportation_amd.distributed import broadcast_model
+    if not use_dist:
+        return None, 0
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    nbytes = broadcast_model(h, fitted=(rank == 0), src=0, device=dev)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) * 1e3, nbytes
 
-    h.reserve(M, args.jvar)          # library scratch of the timed calls: allocated here, not inside the first step
 
-    def step():
-        h.predict_all_dev(xq.data_ptr(), M, mean.data_ptr(), var.data_ptr(), J.data_ptr(),
-                          Jvar.data_ptr() if Jvar is not None else 0, 0)
-
+def timed_steps(torch, dist, h, step, args, dev, use_dist):
+    """W warm-up steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks.  The
+    dominant kernel's duration is read per step from the library's hipEvents on the launch stream."""
     def sync_all():
         torch.cuda.synchronize()
         if use_dist:
@@ -178,6 +263,57 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    return elapsed, float(np.mean(var_ms)), float(np.mean(mj_ms))
+
+
+def pmc_traffic(key, n_source, queries):
+    """HBM-side traffic of the dominant kernel comes from a SEPARATE rocprofv3 --pmc run (profiles/pmc_traffic.json,
+    written by tools/pmc_traffic.py with the workload and commit it was measured on); it is quoted only when this run's
+    workload is the one measured there and the library is the in-tree build."""
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(tpath) or os.environ.get("GPT_HIP_LIB"):
+        return None, None
+    try:
+        rec = json.load(open(tpath)).get(key, {})
+        if (rec.get("n_source"), rec.get("queries")) == (n_source, queries):
+            return rec.get("hbm_bytes_per_launch"), (f"profiles/pmc_traffic.json (rocprofv3 --pmc, separate run, "
+                                                     f"commit {rec.get('commit', '?')})")
+    except Exception:
+        pass
+    return None, None
+
+
+def run_exact(args):
+    torch, dist, h, rank, world, dev, use_dist, ranks_seen = init_ranks(args)
+    N, D, O, M = args.n_source, 3, 3, args.queries
+
+    # ---- fit on rank 0, broadcast the factor (outside the timed region; reported)
+    fit_ms = fit_timings = None
+    if rank == 0:
+        X, Y = synthetic_sources(N, D)
+        ls = np.array([0.1] * D)
+        h.fit(X, Y, ls, 0.1, 1e-4, 1e-10)                  # first call: allocations + code load
+        t0 = time.perf_counter()
+        h.fit(X, Y, ls, 0.1, 1e-4, 1e-10)
+        fit_ms = (time.perf_counter() - t0) * 1e3
+        fit_timings = h.fit_timings()
+    bcast_ms, bcast_bytes = broadcast_fitted(torch, dist, h, rank, dev, use_dist)
+
+    # ---- this rank's query shard, resident in HBM
+    xq_host = np.random.default_rng(1 + rank).uniform(-0.1, 1.1, (M, D))
+    xq = torch.from_numpy(xq_host).to(dev)
+    mean = torch.empty((M, O), dtype=torch.float64, device=dev)
+    var = torch.empty((M,), dtype=torch.float64, device=dev)
+    J = torch.empty((M, O, D), dtype=torch.float64, device=dev)
+    Jvar = torch.empty((M, D), dtype=torch.float64, device=dev) if args.jvar else None
+
+    h.reserve(M, args.jvar)          # library scratch of the timed calls: allocated here, not inside the first step
+
+    def step():
+        h.predict_all_dev(xq.data_ptr(), M, mean.data_ptr(), var.data_ptr(), J.data_ptr(),
+                          Jvar.data_ptr() if Jvar is not None else 0, 0)
+
+    elapsed, kern_ms, mj_ms = timed_steps(torch, dist, h, step, args, dev, use_dist)
 
     # ---- sanity of the timed outputs (finite, variance within [0, c+noise])
     ok = bool(torch.isfinite(mean).all() and torch.isfinite(J).all() and torch.isfinite(var).all()
@@ -186,18 +322,10 @@ def main():
         raise SystemExit("bench: non-finite or out-of-range outputs")
 
     if rank == 0:
-        total_q = world * M * args.steps
-        value = total_q / elapsed
-        kern_ms = float(np.mean(var_ms))
+        value = world * M * args.steps / elapsed
         kflops = var_kernel_flops_per_query(N, D, args.jvar) * M
         achieved = kflops / (kern_ms * 1e-3) / 1e12
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("jvar" if args.jvar else "j", {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic, traffic_source = pmc_traffic("jvar" if args.jvar else "j", N, M)
         out = {
             "metric": "posterior (mean+var+Jacobian) preds/sec, N=8192 source pts, 3-D fp64",
             "value": value, "unit": "predictions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -211,14 +339,107 @@ def main():
             "achieved_tflops_whole_path": value * flops_per_query(N, D, O, args.jvar) / 1e12 / world,
             "roofline": {"bound": "mfma", "kernel": "k_var (variance / Jacobian-variance triangular MFMA GEMM)",
                          "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
-                         "kernel_ms": kern_ms, "mean_jac_kernel_ms": float(np.mean(mj_ms))},
+                         "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel_ms": kern_ms, "mean_jac_kernel_ms": mj_ms},
             "fit_ms": fit_ms, "fit_phases_ms": fit_timings, "bcast_ms": bcast_ms, "bcast_bytes": bcast_bytes,
+            "ranks_seen": ranks_seen,
         }
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(N, D, O, args.cpu_sample, args.jvar)
         else:
             out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    h.close()
+    if use_dist:
+        dist.destroy_process_group()
+
+
+def svgp_flops_per_query(Z, D, T):
+    """SURVEY §8d work model applied to the multi-task model: per task and column Z^2 (+2Z), (1+D) columns; the kernel
+    row (3DZ flop + Z exp) is shared by the tasks; mean + Jacobian contraction 2ZT + 2ZDT + DZ."""
+    var = T * (1 + D) * (Z * Z + 2 * Z) + Z * (3 * D + 1)
+    return var + Z * (2 * T + 2 * D * T + D + 2), var
+
+
+def svgp_synthetic_model(Zn, T=3, D=3, seed=0):
+    """SURVEY §8d cfg5 inputs: inducing points U[0,1]^D, Sigma_pseudo = A A^T / Z + 1e-3 I (A ~ N(0,1)), y_pseudo ~
+    N(0,1), outputscale 1, length-scale 0.2 (the same draws as oracle.svgp_synthetic_problem)."""
+    rng = np.random.default_rng(seed)
+    Z = rng.uniform(0, 1, (Zn, D))
+    Sigma = np.empty((T, Zn, Zn))
+    for t in range(T):
+        A = rng.standard_normal((Zn, Zn))
+        Sigma[t] = A @ A.T / Zn + 1e-3 * np.eye(Zn)
+    y = rng.standard_normal((T, Zn))
+    return Z, Sigma, y, np.ones(T), np.full(D, 0.2)
+
+
+def svgp_cpu_baseline(Z, sample):
+    """The SVGP exact-conversion algebra restated in the reference's arithmetic (numpy float32: it casts with .float()
+    and inverts K_uu + Sigma in fp32; BLAS on all host cores) on a bounded sample of the queries.  kind = "port"."""
+    from oracle import gp_oracle as orc
+    Zp, Sigma, y, osc, ls, Xq = orc.svgp_synthetic_problem(Z, sample)
+    t0 = time.perf_counter()
+    orc.svgp_exact_oracle_fast(Xq[:8], Zp, Sigma, y, osc, ls, dtype=np.float32)      # the T inverses (the "fit")
+    t_fit = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    orc.svgp_exact_oracle_fast(Xq, Zp, Sigma, y, osc, ls, dtype=np.float32)
+    t_all = time.perf_counter() - t0
+    t_pred = max(t_all - t_fit, 1e-9)
+    return {"value": sample / t_pred, "unit": "predictions/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"oracle.svgp_exact_oracle_fast(float32) on {sample} of the queries at Z={Z}, T=D=3 (mean+std+J+J std), "
+                      f"numpy BLAS threads; conversion (3 fp32 inverses) took {t_fit:.2f} s", "fit_s": t_fit}
+
+
+def run_svgp(args):
+    """BASELINE configs[4]: SVGP-MIMO derivative path, 2048 inducing points, T = D = 3, M = 1e6 queries, fp32.
+    A step = mean (M,T), variance (M,T), Jacobian (M,T,D) and Jacobian variance (M,T,D) of one resident batch."""
+    from gaussian_process_transportation_amd import _lib
+    torch, dist, h, rank, world, dev, use_dist, ranks_seen = init_ranks(args)
+    Z, T, D = args.inducing, 3, 3
+    M = args.queries if args.queries != 500_000 else 1_000_000
+    fit_ms = None
+    if rank == 0:
+        Zp, Sigma, y, osc, ls = svgp_synthetic_model(Z, T, D)
+        h.fit_svgp(Zp, y, Sigma, ls, osc, dtype=_lib.GPT_F32)
+        t0 = time.perf_counter()
+        h.fit_svgp(Zp, y, Sigma, ls, osc, dtype=_lib.GPT_F32)
+        fit_ms = (time.perf_counter() - t0) * 1e3
+    bcast_ms, bcast_bytes = broadcast_fitted(torch, dist, h, rank, dev, use_dist)
+    xq = torch.from_numpy(np.random.default_rng(1 + rank).uniform(-0.1, 1.1, (M, D)).astype(np.float32)).to(dev)
+    f32 = torch.float32
+    mean = torch.empty((M, T), dtype=f32, device=dev); var = torch.empty((M, T), dtype=f32, device=dev)
+    J = torch.empty((M, T, D), dtype=f32, device=dev); Jvar = torch.empty((M, T, D), dtype=f32, device=dev)
+    h.reserve(M, True)
+
+    def step():
+        h.predict_all_dev(xq.data_ptr(), M, mean.data_ptr(), var.data_ptr(), J.data_ptr(), Jvar.data_ptr(), 0)
+
+    elapsed, kern_ms, mj_ms = timed_steps(torch, dist, h, step, args, dev, use_dist)
+    ok = bool(torch.isfinite(mean).all() and torch.isfinite(J).all() and torch.isfinite(var).all() and torch.isfinite(Jvar).all()
+              and float(var.min()) >= 0.0 and float(var.max()) <= 1.0 + 1e-5)
+    if not ok:
+        raise SystemExit("bench (svgp): non-finite or out-of-range outputs")
+    if rank == 0:
+        value = world * M * args.steps / elapsed
+        fq, fq_var = svgp_flops_per_query(Z, D, T)
+        achieved = fq_var * M / (kern_ms * 1e-3) / 1e12
+        out = {
+            "metric": "SVGP-MIMO posterior (mean+std+Jacobian+Jacobian std) preds/sec, 2048 inducing pts, 3 tasks, 3-D fp32",
+            "value": value, "unit": "predictions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[4]: SVGP exact conversion, Z={Z} inducing pts, T=D=3, M={M} queries per GPU "
+                                   "per step, mean+std+Jacobian+Jacobian std, fp32 prediction (fp64 factorisation)",
+                       "inducing": Z, "tasks": T, "queries_per_gpu": M},
+            "flops_per_query": fq, "achieved_tflops_whole_path": value * fq / 1e12 / world,
+            "roofline": {"bound": "mfma", "kernel": "k_var<float> (stacked per-task triangular MFMA GEMM, v_mfma_f32_16x16x4_f32)",
+                         "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "traffic_source": None,
+                         "kernel_ms": kern_ms, "mean_jac_kernel_ms": mj_ms},
+            "fit_ms": fit_ms, "bcast_ms": bcast_ms, "bcast_bytes": bcast_bytes, "ranks_seen": ranks_seen,
+        }
+        out["cpu_baseline"] = svgp_cpu_baseline(Z, args.cpu_sample * 5) if world == 1 and args.cpu_sample > 0 else None
         print(json.dumps(out), flush=True)
     h.close()
     if use_dist:

@@ -4,5 +4,9 @@ from .affine_transform import AffineTransform
 from .gaussian_process import GaussianProcess
 from .policy_transportation import PolicyTransportation
 from .gaussian_process_transportation import GaussianProcessTransportation
+from .svgp_exact import StocasticVariationalGaussianProcess, SVGPExactPredictor
+from .svgp_transport import SVGPTransport
 
-__all__ = ["AffineTransform", "GaussianProcessTransportation", "GaussianProcess", "PolicyTransportation"]
+# the reference's three exports first; then the duck-typed caller and the SVGP exact-conversion path
+__all__ = ["AffineTransform", "GaussianProcessTransportation", "GaussianProcess", "PolicyTransportation",
+           "SVGPTransport", "StocasticVariationalGaussianProcess", "SVGPExactPredictor"]

@@ -13,6 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GPT_HIP_LIB") or os.path.join(_HERE, "libgpt_hip.so")   # override: A/B of two builds
 
 GPT_OK, GPT_E_HIP, GPT_E_NOT_PD, GPT_E_ARG, GPT_E_STATE = 0, -1, -2, -3, -4
+GPT_F64, GPT_F32 = 0, 1
+_NP_DTYPE = {GPT_F64: np.float64, GPT_F32: np.float32}
 
 _dp = C.POINTER(C.c_double)
 _vp = C.c_void_p
@@ -27,13 +29,15 @@ SIGNATURES = {
     "gpt_destroy": (None, [_vp]),
     "gpt_set_stream": (C.c_int, [_vp, _vp]),
     "gpt_synchronize": (C.c_int, [_vp]),
+    "gpt_set_dtype": (C.c_int, [_vp, C.c_int]),
     "gpt_fit": (C.c_int, [_vp, _dp, _dp, _i64, C.c_int, C.c_int, _dp, C.c_int, C.c_double, C.c_double, C.c_double]),
     "gpt_fit_kernel": (C.c_int, [_vp, _dp, _dp, _i64, C.c_int, C.c_int, _dp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int]),
     "gpt_fit_noise_matrix": (C.c_int, [_vp, _dp, _dp, _i64, C.c_int, C.c_int, _dp, C.c_int, C.c_double, _dp, C.c_double, C.c_int]),
-    "gpt_predict": (C.c_int, [_vp, _dp, _i64, _dp, _dp]),
-    "gpt_derivative": (C.c_int, [_vp, _dp, _i64, _dp, _dp]),
-    "gpt_dvariance": (C.c_int, [_vp, _dp, _i64, _dp]),
-    "gpt_predict_all": (C.c_int, [_vp, _dp, _i64, _dp, _dp, _dp, _dp, _dp]),
+    "gpt_fit_svgp": (C.c_int, [_vp, _dp, _dp, _dp, _i64, C.c_int, C.c_int, _dp, C.c_int, _dp, C.c_double, C.c_int]),
+    "gpt_predict": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
+    "gpt_derivative": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
+    "gpt_dvariance": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "gpt_predict_all": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "gpt_predict_all_dev": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "gpt_predict_cov": (C.c_int, [_vp, _dp, _i64, _dp, _dp]),
     "gpt_export": (C.c_int, [_vp, _dp, _dp]),
@@ -42,7 +46,11 @@ SIGNATURES = {
     "gpt_lml_gradient": (C.c_int, [_vp, _dp, _dp]),
     "gpt_factor_blob": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
     "gpt_factor_alloc": (C.c_int, [_vp, _i64, C.c_int, C.c_int, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
+    "gpt_factor_alloc_model": (C.c_int, [_vp, _i64, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
     "gpt_factor_commit": (C.c_int, [_vp]),
+    "gpt_model_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "gpt_debug_var_plan": (C.c_int, [_i64, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_i64), C.POINTER(C.c_int),
+                                     C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "gpt_info": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_i64)]),
     "gpt_fit_timings": (C.c_int, [_vp, _dp, C.c_int]),
     "gpt_set_profiling": (C.c_int, [_vp, C.c_int]),
@@ -119,15 +127,42 @@ def require_gpu() -> int:
     return n
 
 
-def as_f64(a, ndim=None) -> np.ndarray:
-    a = np.ascontiguousarray(a, dtype=np.float64)
+def as_f64(a, ndim=None, what="Input", dtype=np.float64) -> np.ndarray:
+    """C-contiguous array of `dtype`, finite.  scikit-learn's check_array refuses NaN / infinity in fit and predict
+    inputs with a ValueError (sklearn/utils/validation.py, reached from _gpr.py:262 and :415); the kernels would
+    otherwise turn a NaN query into a prior-looking prediction (the table exp clamps its argument).  The
+    device-pointer API (`predict_all_dev`) leaves this check to the caller."""
+    a = np.ascontiguousarray(a, dtype=dtype)
     if ndim is not None and a.ndim != ndim:
         raise ValueError(f"expected a {ndim}-D array, got shape {a.shape}")
+    if not np.isfinite(a).all():
+        raise ValueError(f"{what} contains NaN or infinity.")
     return a
 
 
 def dptr(a):
     return None if a is None else a.ctypes.data_as(_dp)
+
+
+def vptr(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+def debug_var_plan(n_columns, n_iblocks, n_tasks, n_workgroups, order=-1):
+    """The work decomposition of the variance kernel (csrc/gpt_plan.h) as numpy arrays; host code, no GPU."""
+    lib = load()
+    counts = (_i64 * 8)()
+    ip = C.POINTER(C.c_int)
+    check(lib.gpt_debug_var_plan(n_columns, n_iblocks, n_tasks, n_workgroups, order, counts, None, None, None, None))
+    item_begin = np.zeros(n_workgroups + 1, dtype=np.int32)
+    items = np.zeros((max(counts[0], 1), 8), dtype=np.int32)
+    fin = np.zeros((max(counts[6], 1), 2), dtype=np.int32)
+    splits = np.zeros((max(counts[1], 1), 3), dtype=np.int32)
+    check(lib.gpt_debug_var_plan(n_columns, n_iblocks, n_tasks, n_workgroups, order, counts, item_begin.ctypes.data_as(ip),
+                                 items.ctypes.data_as(ip), fin.ctypes.data_as(ip), splits.ctypes.data_as(ip)))
+    return {"n_items": counts[0], "n_splits": counts[1], "n_slots": counts[2], "n_vslots": counts[3], "ncb": counts[4],
+            "nfull": counts[5], "order": counts[7], "item_begin": item_begin, "items": items[:counts[0]],
+            "fin": fin[:counts[6]], "splits": splits[:counts[1]]}
 
 
 class Handle:
@@ -153,29 +188,56 @@ class Handle:
             pass
 
     # ---- fit / export
+    def set_dtype(self, dtype):
+        """Element type of the models fitted from now on: GPT_F64 (default) or GPT_F32."""
+        check(self.lib.gpt_set_dtype(self._h, int(dtype)), "gpt_set_dtype")
+
     def fit(self, X, Y, length_scale, constant_value, noise_level, alpha, kernel_type=0):
         """kernel_type: 0 RBF, 1/2/3 Matern nu = 0.5 / 1.5 / 2.5 (GPT_KERNEL_* of include/gpt_hip.h)."""
-        X = as_f64(X, 2)
-        Y = as_f64(Y, 2)
-        ls = as_f64(np.atleast_1d(length_scale), 1)
+        X = as_f64(X, 2, "X")
+        Y = as_f64(Y, 2, "y")
+        ls = as_f64(np.atleast_1d(length_scale), 1, "length_scale")
         N, D = X.shape
         if Y.shape[0] != N:
             raise ValueError("X and Y have different numbers of rows")
+        if not 1 <= D <= 3:
+            raise ValueError(f"X has {D} features: this GPU path supports input dimension D = 1, 2 or 3 only")
         check(self.lib.gpt_fit_kernel(self._h, dptr(X), dptr(Y), N, D, Y.shape[1], dptr(ls), ls.size,
                                       float(constant_value), float(noise_level), float(alpha), int(kernel_type)), "gpt_fit")
 
     def fit_noise_matrix(self, X, Y, length_scale, constant_value, Sigma, alpha=0.0, kernel_type=0):
         """K = c k(X,X) + Sigma (full SPD (N,N)) + alpha I — the SVGP exact-conversion model."""
-        X = as_f64(X, 2)
-        Y = as_f64(Y, 2)
-        Sigma = as_f64(Sigma, 2)
-        ls = as_f64(np.atleast_1d(length_scale), 1)
+        X = as_f64(X, 2, "X")
+        Y = as_f64(Y, 2, "y")
+        Sigma = as_f64(Sigma, 2, "Sigma")
+        ls = as_f64(np.atleast_1d(length_scale), 1, "length_scale")
         N, D = X.shape
         if Y.shape[0] != N or Sigma.shape != (N, N):
             raise ValueError("X, Y and Sigma disagree on the number of points")
         check(self.lib.gpt_fit_noise_matrix(self._h, dptr(X), dptr(Y), N, D, Y.shape[1], dptr(ls), ls.size,
                                             float(constant_value), dptr(Sigma), float(alpha), int(kernel_type)),
               "gpt_fit_noise_matrix")
+
+    def fit_svgp(self, Z, y, Sigma, length_scale, outputscale, jitter=0.0, dtype=GPT_F64):
+        """The multi-task SVGP exact-conversion model in one handle (gpt_fit_svgp): Z (N,D), y (T,N), Sigma (T,N,N),
+        outputscale (T,), length_scale (1 or D)."""
+        Z = as_f64(Z, 2, "Z")
+        y = as_f64(y, 2, "y")
+        Sigma = as_f64(Sigma, 3, "Sigma")
+        ls = as_f64(np.atleast_1d(length_scale), 1, "length_scale")
+        osc = as_f64(np.atleast_1d(outputscale), 1, "outputscale")
+        N, D = Z.shape
+        T = y.shape[0]
+        if y.shape != (T, N) or Sigma.shape != (T, N, N) or osc.shape != (T,):
+            raise ValueError("expected y (T,N), Sigma (T,N,N), outputscale (T,)")
+        check(self.lib.gpt_fit_svgp(self._h, dptr(Z), dptr(y), dptr(Sigma), N, D, T, dptr(ls), ls.size, dptr(osc),
+                                    float(jitter), int(dtype)), "gpt_fit_svgp")
+
+    def model_info(self):
+        """(n_tasks, dtype) of the fitted model."""
+        nt, dt = C.c_int(), C.c_int()
+        check(self.lib.gpt_model_info(self._h, C.byref(nt), C.byref(dt)), "gpt_model_info")
+        return nt.value, dt.value
 
     def info(self):
         N, NP, D, O = _i64(), _i64(), C.c_int(), C.c_int()
@@ -213,25 +275,30 @@ class Handle:
 
     # ---- predict (host buffers)
     def predict_all(self, Xq, mean=False, var=False, J=False, Jvar=False, dvar=False):
+        """Arrays come back in the model's element type (float64, or float32 for a GPT_F32 model); the multi-task
+        model returns var (M,T) and Jvar (M,T,D)."""
         N, D, O, _ = self.info()
-        Xq = as_f64(Xq, 2)
+        nt, dt = self.model_info()
+        ty = _NP_DTYPE[dt]
+        Xq = as_f64(Xq, 2, "X", dtype=ty)
         if Xq.shape[1] != D:
             raise ValueError(f"query has {Xq.shape[1]} features, model was fitted with {D}")
         M = Xq.shape[0]
+        vshape, jvshape = ((M,), (M, D)) if nt == 1 else ((M, nt), (M, nt, D))
         out = {
-            "mean": np.empty((M, O)) if mean else None,
-            "var": np.empty(M) if var else None,
-            "J": np.empty((M, O, D)) if J else None,
-            "Jvar": np.empty((M, D)) if Jvar else None,
-            "dvar": np.empty((D, M)) if dvar else None,
+            "mean": np.empty((M, O), dtype=ty) if mean else None,
+            "var": np.empty(vshape, dtype=ty) if var else None,
+            "J": np.empty((M, O, D), dtype=ty) if J else None,
+            "Jvar": np.empty(jvshape, dtype=ty) if Jvar else None,
+            "dvar": np.empty((D, M), dtype=ty) if dvar else None,
         }
-        check(self.lib.gpt_predict_all(self._h, dptr(Xq), M, dptr(out["mean"]), dptr(out["var"]), dptr(out["J"]),
-                                       dptr(out["Jvar"]), dptr(out["dvar"])), "gpt_predict_all")
+        check(self.lib.gpt_predict_all(self._h, vptr(Xq), M, vptr(out["mean"]), vptr(out["var"]), vptr(out["J"]),
+                                       vptr(out["Jvar"]), vptr(out["dvar"])), "gpt_predict_all")
         return out
 
     def predict_cov(self, Xq):
         N, D, O, _ = self.info()
-        Xq = as_f64(Xq, 2)
+        Xq = as_f64(Xq, 2, "X")
         if Xq.shape[1] != D:
             raise ValueError(f"query has {Xq.shape[1]} features, model was fitted with {D}")
         M = Xq.shape[0]
@@ -269,9 +336,10 @@ class Handle:
         check(self.lib.gpt_factor_blob(self._h, C.byref(p), C.byref(n)), "gpt_factor_blob")
         return p.value, n.value
 
-    def factor_alloc(self, N, D, O):
+    def factor_alloc(self, N, D, O, n_tasks=1, dtype=GPT_F64):
         p, n = _vp(), C.c_size_t()
-        check(self.lib.gpt_factor_alloc(self._h, int(N), int(D), int(O), C.byref(p), C.byref(n)), "gpt_factor_alloc")
+        check(self.lib.gpt_factor_alloc_model(self._h, int(N), int(D), int(O), int(n_tasks), int(dtype), C.byref(p),
+                                              C.byref(n)), "gpt_factor_alloc_model")
         return p.value, n.value
 
     def factor_commit(self):

@@ -2,10 +2,12 @@
 // buffers, prepares scaled/padded inputs, sequences the kernels of gpt_fit.hip / gpt_predict.hip
 // on one HIP stream and maps failures to error codes.
 #include "gpt_common.h"
+#include "gpt_plan.h"
 #include "../../include/gpt_hip.h"
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -28,67 +30,158 @@ int fail(int code, const std::string& msg) {
             return fail(GPT_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));            \
     } while (0)
 
-constexpr double MAGIC = 1196446769.0;   // "GPT1"
+constexpr double MAGIC = 1196446770.0;   // "GPT2": header layout of this version
 constexpr int HDR_DOUBLES = 64;
+constexpr int HDR_TASK_C = 16;           // hdr[16 + t]: prior variance of task t (constant_value / outputscale)
+constexpr int MAX_TASKS = 32;
 constexpr int64_t HOST_CHUNK = 1 << 17;  // queries per chunk of the host-pointer API (two chunks in flight)
 
+// Model blob: [header: 64 doubles][Xs: NP x 4][A4: npass x NP x 4][Wf: ntask tile sets + overrun], the three arrays
+// in the model's element type.  Offsets in bytes.
 struct Layout {
-    int64_t N, NP;
-    int D, O, npass;
-    size_t off_xs, off_a4, off_wf, total;   // in doubles
+    int64_t N = 0, NP = 0;
+    int D = 0, O = 0, npass = 0, ntask = 1, dtype = DT_F64;
+    size_t esz = 8, off_xs = 0, off_a4 = 0, off_wf = 0, total = 0;
+    bool same_shape(const Layout& o) const { return total == o.total && NP == o.NP && npass == o.npass && ntask == o.ntask && dtype == o.dtype; }
 };
 
-Layout make_layout(int64_t N, int D, int O) {
+Layout make_layout(int64_t N, int D, int O, int ntask, int dtype) {
     Layout l;
-    l.N = N; l.D = D; l.O = O;
+    l.N = N; l.D = D; l.O = O; l.ntask = ntask; l.dtype = dtype;
+    l.esz = dtype == DT_F32 ? sizeof(float) : sizeof(double);
     l.NP = (N + PAD_N - 1) / PAD_N * PAD_N;
     l.npass = (O + 3) / 4;
-    l.off_xs = HDR_DOUBLES;
-    l.off_a4 = l.off_xs + (size_t)l.NP * 4;
-    l.off_wf = l.off_a4 + (size_t)l.npass * l.NP * 4;
-    l.total = l.off_wf + wf_doubles((int)l.NP);
+    l.off_xs = HDR_DOUBLES * sizeof(double);
+    l.off_a4 = l.off_xs + (size_t)l.NP * 4 * l.esz;
+    l.off_wf = l.off_a4 + (size_t)l.npass * l.NP * 4 * l.esz;
+    l.total = l.off_wf + ((size_t)ntask * wf_elems((int)l.NP) + wf_overrun_elems()) * l.esz;
     return l;
 }
 
+enum { ST_Q = 0, ST_MEAN, ST_VAR, ST_J, ST_JVAR, ST_DVAR, ST_COUNT };
+
 }  // namespace
+
+// ---- host side of the variance kernel: workgroup count, scratch buffers and the (cached) work plan of a launch shape
+namespace gpt {
+
+int var_workgroups() {
+    static int n[MAX_DEVICES] = {};
+    const int dev = current_device();
+    if (n[dev] == 0) {
+        int v = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) v = prop.multiProcessorCount;
+        if (v <= 0) v = 256;
+        const char* e = getenv("GPT_VAR_WGS");
+        if (e && atoi(e) > 0) v = atoi(e);
+        n[dev] = v;
+    }
+    return n[dev];
+}
+
+static int var_cols_per_query(const KernelParams& p, int ncomp) { return (ncomp == 3) ? p.D : ncomp; }   // 3 = Jacobian variance alone
+
+void var_release(VarWorkspace& ws) {
+    for (void** pp : {&ws.slab, &ws.vslab, &ws.bscratch, &ws.plan_dev}) { if (*pp) (void)hipFree(*pp); *pp = nullptr; }
+    ws.slab_bytes = ws.vslab_bytes = ws.bscratch_bytes = ws.plan_bytes = 0;
+    delete ws.plan;
+    ws.plan = nullptr;
+    ws.key_cols = -1;
+}
+
+hipError_t var_prepare(VarWorkspace& ws, hipStream_t s, const KernelParams& p, int64_t M, int ncomp) {
+    const size_t esz = p.dtype == DT_F32 ? sizeof(float) : sizeof(double);
+    const int P = var_workgroups();
+    const int nbi = p.NP / WT;
+    const int64_t ncols = M * var_cols_per_query(p, ncomp);
+    bool synced = false;
+    auto grow = [&](void*& buf, size_t& have, size_t need) -> hipError_t {
+        if (need <= have) return hipSuccess;
+        if (!synced) { if (hipError_t e = hipStreamSynchronize(s)) return e; synced = true; }   // work in flight may still use the old buffers
+        if (buf) (void)hipFree(buf);
+        buf = nullptr; have = 0;
+        if (hipError_t e = hipMalloc(&buf, need)) return e;
+        have = need;
+        ++ws.allocs;
+        return hipSuccess;
+    };
+    const bool same = ws.plan && ws.key_cols == ncols && ws.key_nbi == nbi && ws.key_ntask == p.ntask && ws.key_P == P;
+    if (!same) {
+        int order_env = -1;                                  // diagnostic override of the tail order (README)
+        if (const char* e = getenv("GPT_VAR_TAIL_ORDER")) order_env = atoi(e);
+        VarPlanHost* np = new VarPlanHost(build_var_plan(ncols, nbi, p.ntask, P, order_env));
+        // device image: [item_begin (P+1) | items | fin | splits], each part 16-byte aligned
+        auto al = [](size_t b) { return (b + 15) / 16 * 16; };
+        const size_t b0 = al((size_t)(P + 1) * sizeof(int)), b1 = al(np->items.size() * sizeof(VarItem)),
+                     b2 = al(np->fin.size() * sizeof(int)), b3 = al(np->splits.size() * sizeof(VarSplit));
+        const size_t total = b0 + b1 + b2 + b3 + 16;
+        // the previous plan may still be read by a launch in flight: wait before overwriting it
+        if (!synced) { if (hipError_t e = hipStreamSynchronize(s)) { delete np; return e; } synced = true; }
+        if (hipError_t e = grow(ws.plan_dev, ws.plan_bytes, total)) { delete np; return e; }
+        std::vector<unsigned char> img(total, 0);
+        memcpy(img.data(), np->item_begin.data(), (size_t)(P + 1) * sizeof(int));
+        if (!np->items.empty()) memcpy(img.data() + b0, np->items.data(), np->items.size() * sizeof(VarItem));
+        if (!np->fin.empty()) memcpy(img.data() + b0 + b1, np->fin.data(), np->fin.size() * sizeof(int));
+        if (!np->splits.empty()) memcpy(img.data() + b0 + b1 + b2, np->splits.data(), np->splits.size() * sizeof(VarSplit));
+        if (hipError_t e = hipMemcpy(ws.plan_dev, img.data(), total, hipMemcpyHostToDevice)) { delete np; return e; }
+        unsigned char* base = static_cast<unsigned char*>(ws.plan_dev);
+        np->d.item_begin = reinterpret_cast<const int*>(base);
+        np->d.items = reinterpret_cast<const VarItem*>(base + b0);
+        np->d.fin = reinterpret_cast<const int*>(base + b0 + b1);
+        np->d.splits = reinterpret_cast<const VarSplit*>(base + b0 + b1 + b2);
+        delete ws.plan;
+        ws.plan = np;
+        ws.key_cols = ncols; ws.key_nbi = nbi; ws.key_ntask = p.ntask; ws.key_P = P;
+    }
+    if (hipError_t e = grow(ws.slab, ws.slab_bytes, (size_t)(ws.plan->n_slots + 1) * VAR_SLOT * esz)) return e;
+    if (hipError_t e = grow(ws.vslab, ws.vslab_bytes, (size_t)ws.plan->n_vslots * VAR_VSLOT * esz)) return e;
+    if (hipError_t e = grow(ws.bscratch, ws.bscratch_bytes, (size_t)P * p.NP * VAR_COLS * esz)) return e;
+    return hipSuccess;
+}
+
+}  // namespace gpt
 
 struct gpt_handle {
     int device = 0;
+    int dtype_next = DT_F64;       // element type of models fitted from now on (gpt_set_dtype)
     hipStream_t own_stream = nullptr, stream = nullptr;
     // model blob
-    double* blob = nullptr;
+    unsigned char* blob = nullptr;
     Layout lay{};
     bool have_layout = false, committed = false;
     KernelParams p{};
     double jitter = 0, ls[3] = {1, 1, 1};
     int n_ls = 1;
-    // fit workspace
-    double *dK = nullptr, *dW = nullptr, *dY4 = nullptr, *dT4 = nullptr, *dscal = nullptr;
+    // fit workspace (fp64)
+    double *dK = nullptr, *dW = nullptr, *dY4 = nullptr, *dT4 = nullptr, *dTa = nullptr, *dXs64 = nullptr, *dA64 = nullptr, *dscal = nullptr;
+    double* dScr = nullptr;        // scratch of the triangular inverse (NP^2/4) and of alpha's backward pass
     int* dinfo = nullptr;
     int64_t ws_np = 0;
     int ws_npass = 0;
-    bool have_factor_ws = false;   // dK/dW hold L / L^-1 of the current model
+    bool have_L = false;           // dK holds L of the committed model (gpt_export, gpt_lml)
+    bool have_W = false;           // dW holds L^-1 of the committed model (gpt_predict_cov, gpt_lml_gradient, gpt_export_inverse_factor)
     std::vector<double> hostY;     // filtered targets (N,O) for the LML
-    // staging of the host-pointer API
+    // staging of the host-pointer API, grow-only per buffer
     // (two sets: while the results of one chunk travel to the host on `copy_stream`, the next chunk computes)
-    struct Staging { double *q = nullptr, *mean = nullptr, *var = nullptr, *J = nullptr, *Jvar = nullptr, *dvar = nullptr; } st[2];
-    int64_t scap = 0;
-    int sD = 0, sO = 0;
+    struct Staging { void* buf[ST_COUNT] = {}; size_t bytes[ST_COUNT] = {}; } st[2];
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_done[2] = {}, ev_copied[2] = {};   // chunk computed / chunk's outputs copied out, per staging set
     double fit_ms[6] = {0, 0, 0, 0, 0, 0};
     hipEvent_t ev[7] = {};
     // per-kernel timing of the last predict (gpt_set_profiling)
     bool profiling = false, pred_mj = false, pred_var = false;
-    double* slab = nullptr;        // partial column sums of the variance kernel (grow-only)
-    size_t slab_cap = 0;
-    double* bscratch = nullptr;    // per-workgroup B-fragment images of the variance kernel (grow-only)
-    size_t bscratch_cap = 0;
+    VarWorkspace vws;              // scratch + cached plan of the variance kernel
+    double* lml_partial = nullptr; // partial sums of the LML gradient (grow-only)
+    size_t lml_partial_cap = 0;
+    unsigned char* cov_buf = nullptr;   // scratch of gpt_predict_cov (grow-only)
+    size_t cov_cap = 0;
     hipEvent_t pev[4] = {};
 
-    double* dXs() const { return blob + lay.off_xs; }
-    double* dA4() const { return blob + lay.off_a4; }
-    double* dWf() const { return blob + lay.off_wf; }
+    void* dXs() const { return blob + lay.off_xs; }
+    void* dA4() const { return blob + lay.off_a4; }
+    void* dWf() const { return blob + lay.off_wf; }
+    const double* dHdr() const { return reinterpret_cast<const double*>(blob); }
 };
 
 namespace {
@@ -99,28 +192,27 @@ int set_device(gpt_handle* h) {
 }
 
 void free_staging(gpt_handle* h) {
-    for (auto& t : h->st) {
-        double** ptrs[] = {&t.q, &t.mean, &t.var, &t.J, &t.Jvar, &t.dvar};
-        for (auto pp : ptrs) { if (*pp) (void)hipFree(*pp); *pp = nullptr; }
-    }
-    h->scap = 0;
+    for (auto& t : h->st)
+        for (int i = 0; i < ST_COUNT; ++i) { if (t.buf[i]) (void)hipFree(t.buf[i]); t.buf[i] = nullptr; t.bytes[i] = 0; }
 }
 
 void free_workspace(gpt_handle* h) {
-    double** ptrs[] = {&h->dK, &h->dW, &h->dY4, &h->dT4, &h->dscal};
+    double** ptrs[] = {&h->dK, &h->dW, &h->dY4, &h->dT4, &h->dTa, &h->dXs64, &h->dA64, &h->dscal, &h->dScr};
     for (auto pp : ptrs) { if (*pp) (void)hipFree(*pp); *pp = nullptr; }
     if (h->dinfo) (void)hipFree(h->dinfo);
     h->dinfo = nullptr;
-    h->ws_np = 0; h->ws_npass = 0; h->have_factor_ws = false;
+    h->ws_np = 0; h->ws_npass = 0; h->have_L = h->have_W = false;
 }
 
 int ensure_blob(gpt_handle* h, const Layout& l) {
-    if (h->blob && h->have_layout && h->lay.total == l.total && h->lay.NP == l.NP && h->lay.npass == l.npass) {
+    if (h->blob && h->have_layout && h->lay.same_shape(l)) {
         h->lay = l;
         return GPT_OK;
     }
+    HIPCHK(hipStreamSynchronize(h->stream));
     if (h->blob) { (void)hipFree(h->blob); h->blob = nullptr; }
-    HIPCHK(hipMalloc(&h->blob, l.total * sizeof(double)));
+    h->have_layout = false;
+    HIPCHK(hipMalloc(&h->blob, l.total));
     h->lay = l;
     h->have_layout = true;
     return GPT_OK;
@@ -128,38 +220,45 @@ int ensure_blob(gpt_handle* h, const Layout& l) {
 
 int ensure_workspace(gpt_handle* h, int64_t NP, int npass) {
     if (h->ws_np == NP && h->ws_npass >= npass && h->dK) return GPT_OK;
+    HIPCHK(hipStreamSynchronize(h->stream));
     free_workspace(h);
     HIPCHK(hipMalloc(&h->dK, (size_t)NP * NP * sizeof(double)));
     HIPCHK(hipMalloc(&h->dW, (size_t)NP * NP * sizeof(double)));
     HIPCHK(hipMalloc(&h->dY4, (size_t)npass * NP * 4 * sizeof(double)));
+    HIPCHK(hipMalloc(&h->dA64, (size_t)npass * NP * 4 * sizeof(double)));
     HIPCHK(hipMalloc(&h->dT4, (size_t)NP * 4 * sizeof(double)));
+    HIPCHK(hipMalloc(&h->dTa, (size_t)NP * 4 * sizeof(double)));
+    HIPCHK(hipMalloc(&h->dXs64, (size_t)NP * 4 * sizeof(double)));
     HIPCHK(hipMalloc(&h->dscal, 8 * sizeof(double)));
     HIPCHK(hipMalloc(&h->dinfo, sizeof(int)));
+    {
+        const size_t a = (size_t)NP * NP / 4, b = (size_t)(NP / 512) * NP * 4;
+        HIPCHK(hipMalloc(&h->dScr, (a > b ? a : b) * sizeof(double)));
+    }
     h->ws_np = NP; h->ws_npass = npass;
     return GPT_OK;
 }
 
-int ensure_staging(gpt_handle* h, int64_t cap, int D, int O) {
-    if (h->scap >= cap && h->sD == D && h->sO == O) return GPT_OK;
+// one staging buffer of one set, grow-only; only what a call asks for is ever allocated
+int ensure_stage(gpt_handle* h, int set, int which, size_t bytes) {
+    gpt_handle::Staging& t = h->st[set];
+    if (t.bytes[which] >= bytes) return GPT_OK;
     HIPCHK(hipStreamSynchronize(h->stream));
     if (h->copy_stream) HIPCHK(hipStreamSynchronize(h->copy_stream));
-    free_staging(h);
-    for (auto& t : h->st) {
-        HIPCHK(hipMalloc(&t.q, (size_t)cap * D * sizeof(double)));
-        HIPCHK(hipMalloc(&t.mean, (size_t)cap * O * sizeof(double)));
-        HIPCHK(hipMalloc(&t.var, (size_t)cap * sizeof(double)));
-        HIPCHK(hipMalloc(&t.J, (size_t)cap * O * D * sizeof(double)));
-        HIPCHK(hipMalloc(&t.Jvar, (size_t)cap * D * sizeof(double)));
-        HIPCHK(hipMalloc(&t.dvar, (size_t)cap * D * sizeof(double)));
+    if (t.buf[which]) (void)hipFree(t.buf[which]);
+    t.buf[which] = nullptr; t.bytes[which] = 0;
+    HIPCHK(hipMalloc(&t.buf[which], bytes));
+    t.bytes[which] = bytes;
+    return GPT_OK;
+}
+
+int ensure_copy_stream(gpt_handle* h) {
+    if (h->copy_stream) return GPT_OK;
+    HIPCHK(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+        HIPCHK(hipEventCreateWithFlags(&h->ev_done[i], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_copied[i], hipEventDisableTiming));
     }
-    if (!h->copy_stream) {
-        HIPCHK(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
-        for (int i = 0; i < 2; ++i) {
-            HIPCHK(hipEventCreateWithFlags(&h->ev_done[i], hipEventDisableTiming));
-            HIPCHK(hipEventCreateWithFlags(&h->ev_copied[i], hipEventDisableTiming));
-        }
-    }
-    h->scap = cap; h->sD = D; h->sO = O;
     return GPT_OK;
 }
 
@@ -169,12 +268,70 @@ void fill_params(gpt_handle* h, const double* hdr) {
     p.c = hdr[5]; p.noise = hdr[6];
     p.lnc = std::log(hdr[5]);
     p.ktype = (int)hdr[13];
+    p.ntask = (int)hdr[14];
+    p.dtype = (int)hdr[15];
     h->jitter = hdr[7];
     h->n_ls = (int)hdr[11];
     for (int d = 0; d < 3; ++d) {
         h->ls[d] = hdr[8 + d];
         p.inv_ls[d] = (d < p.D) ? 1.0 / hdr[8 + d] : 0.0;
     }
+}
+
+int check_geometry(const char* who, int64_t N, int D, int O, const double* length_scale, int n_ls) {
+    if (N < 1 || N > (1 << 20)) return fail(GPT_E_ARG, std::string(who) + ": N out of range");
+    if (D < 1 || D > 3) return fail(GPT_E_ARG, std::string(who) + ": D must be 1, 2 or 3");
+    if (O < 1) return fail(GPT_E_ARG, std::string(who) + ": O must be >= 1");
+    if (n_ls != 1 && n_ls != D) return fail(GPT_E_ARG, std::string(who) + ": length_scale must have 1 or D entries");
+    for (int d = 0; d < n_ls; ++d)
+        if (!(length_scale[d] > 0.0)) return fail(GPT_E_ARG, std::string(who) + ": length_scale must be > 0");
+    return GPT_OK;
+}
+
+// Header + scaled, padded sources: to the fp64 workspace image (what the fit kernels read) and, in the model's element
+// type, to the blob.  hdr is complete on return (task priors at hdr[16..] are the caller's).
+int upload_sources(gpt_handle* h, const Layout& l, const double* X, std::vector<double>& hdr, const double* length_scale,
+                   int n_ls, double constant_value, double noise_level, double alpha_jitter, int kernel_type) {
+    hdr.assign(HDR_DOUBLES, 0.0);
+    hdr[0] = MAGIC; hdr[1] = (double)l.N; hdr[2] = (double)l.NP; hdr[3] = l.D; hdr[4] = l.O;
+    hdr[5] = constant_value; hdr[6] = noise_level; hdr[7] = alpha_jitter;
+    for (int d = 0; d < 3; ++d) hdr[8 + d] = (d < l.D) ? length_scale[n_ls == 1 ? 0 : d] : 1.0;
+    hdr[11] = n_ls; hdr[12] = l.npass; hdr[13] = kernel_type; hdr[14] = l.ntask; hdr[15] = l.dtype;
+    fill_params(h, hdr.data());
+    const size_t NP = (size_t)l.NP;
+    std::vector<double> xs(NP * 4, 0.0);
+    for (int64_t i = 0; i < l.N; ++i)
+        for (int d = 0; d < l.D; ++d) xs[(size_t)i * 4 + d] = X[i * l.D + d] * h->p.inv_ls[d];
+    hipStream_t s = h->stream;
+    HIPCHK(hipMemcpyAsync(h->dXs64, xs.data(), xs.size() * sizeof(double), hipMemcpyHostToDevice, s));
+    if (l.dtype == DT_F32) {
+        std::vector<float> xf(xs.begin(), xs.end());
+        HIPCHK(hipMemcpyAsync(h->dXs(), xf.data(), xf.size() * sizeof(float), hipMemcpyHostToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));
+    } else {
+        HIPCHK(hipMemcpyAsync(h->dXs(), xs.data(), xs.size() * sizeof(double), hipMemcpyHostToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));   // host vectors go out of scope
+    }
+    return GPT_OK;
+}
+
+// K -> L (in dK), W = L^-1 (in dW); K's Gram part from dXs64, optional dense SPD addend Sigma (host, N x N)
+int factorise(gpt_handle* h, int64_t N, int NP, int kernel_type, double c, double diag_add, const double* Sigma) {
+    hipStream_t s = h->stream;
+    HIPCHK(hipMemsetAsync(h->dinfo, 0, sizeof(int), s));
+    HIPCHK(hipMemsetAsync(h->dW, 0, (size_t)NP * NP * sizeof(double), s));
+    launch_gram(s, h->dXs64, (int)N, NP, kernel_type, c, diag_add, h->dK);
+    if (Sigma) {      // K += Sigma: staged through dW (not in use until the factorisation starts)
+        HIPCHK(hipMemcpyAsync(h->dW, Sigma, (size_t)N * N * sizeof(double), hipMemcpyHostToDevice, s));
+        launch_add_lower(s, h->dK, h->dW, (int)N, NP);
+        HIPCHK(hipMemsetAsync(h->dW, 0, (size_t)NP * NP * sizeof(double), s));
+    }
+    HIPCHK(hipEventRecord(h->ev[1], s));
+    launch_potrf(s, h->dK, h->dW, NP, h->dinfo);
+    HIPCHK(hipEventRecord(h->ev[2], s));
+    launch_trinv(s, h->dK, h->dW, NP, h->dScr);
+    HIPCHK(hipEventRecord(h->ev[3], s));
+    return GPT_OK;
 }
 
 }  // namespace
@@ -188,12 +345,12 @@ int gpt_device_count(void) {
 }
 
 const char* gpt_last_error(void) { return g_err.c_str(); }
-const char* gpt_version(void) { return "gpt_hip 0.1 (gfx950)"; }
+const char* gpt_version(void) { return "gpt_hip 0.2 (gfx950)"; }
 
 int gpt_create(gpt_handle** out, int device) {
     if (!out) return fail(GPT_E_ARG, "gpt_create: out is NULL");
     int n = gpt_device_count();
-    if (device < 0 || device >= n) return fail(GPT_E_ARG, "gpt_create: no such HIP device");
+    if (device < 0 || device >= n || device >= MAX_DEVICES) return fail(GPT_E_ARG, "gpt_create: no such HIP device");
     HIPCHK(hipSetDevice(device));
     gpt_handle* h = new gpt_handle();
     h->device = device;
@@ -219,9 +376,10 @@ void gpt_destroy(gpt_handle* h) {
     if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
     free_staging(h);
     free_workspace(h);
+    var_release(h->vws);
     if (h->blob) (void)hipFree(h->blob);
-    if (h->slab) (void)hipFree(h->slab);
-    if (h->bscratch) (void)hipFree(h->bscratch);
+    if (h->lml_partial) (void)hipFree(h->lml_partial);
+    if (h->cov_buf) (void)hipFree(h->cov_buf);
     for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : h->pev) if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : h->ev_done) if (ev) (void)hipEventDestroy(ev);
@@ -241,6 +399,13 @@ int gpt_synchronize(gpt_handle* h) {
     if (!h) return fail(GPT_E_ARG, "gpt_synchronize: NULL handle");
     if (int rc = set_device(h)) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));
+    return GPT_OK;
+}
+
+int gpt_set_dtype(gpt_handle* h, int dtype) {
+    if (!h) return fail(GPT_E_ARG, "gpt_set_dtype: NULL handle");
+    if (dtype != GPT_F64 && dtype != GPT_F32) return fail(GPT_E_ARG, "gpt_set_dtype: dtype must be GPT_F64 or GPT_F32");
+    h->dtype_next = dtype;
     return GPT_OK;
 }
 
@@ -267,69 +432,7 @@ int gpt_fit_noise_matrix(gpt_handle* h, const double* X, const double* Y, int64_
     return fit_impl(h, X, Y, N, D, O, length_scale, n_ls, constant_value, 0.0, alpha_jitter, kernel_type, Sigma);
 }
 
-static int fit_impl(gpt_handle* h, const double* X, const double* Y, int64_t N, int D, int O,
-                    const double* length_scale, int n_ls, double constant_value, double noise_level,
-                    double alpha_jitter, int kernel_type, const double* Sigma) {
-    if (!h || !X || !Y || !length_scale) return fail(GPT_E_ARG, "gpt_fit: NULL argument");
-    if (kernel_type < GPT_KERNEL_RBF || kernel_type > GPT_KERNEL_MATERN52) return fail(GPT_E_ARG, "gpt_fit: unknown kernel_type");
-    if (N < 1 || N > (1 << 20)) return fail(GPT_E_ARG, "gpt_fit: N out of range");
-    if (D < 1 || D > 3) return fail(GPT_E_ARG, "gpt_fit: D must be 1, 2 or 3");
-    if (O < 1) return fail(GPT_E_ARG, "gpt_fit: O must be >= 1");
-    if (n_ls != 1 && n_ls != D) return fail(GPT_E_ARG, "gpt_fit: length_scale must have 1 or D entries");
-    for (int d = 0; d < n_ls; ++d)
-        if (!(length_scale[d] > 0.0)) return fail(GPT_E_ARG, "gpt_fit: length_scale must be > 0");
-    if (!(constant_value > 0.0) || !(noise_level >= 0.0) || !(alpha_jitter >= 0.0))
-        return fail(GPT_E_ARG, "gpt_fit: constant_value > 0, noise_level >= 0, alpha >= 0 required");
-    if (int rc = set_device(h)) return rc;
-    h->committed = false;
-    const Layout l = make_layout(N, D, O);
-    if (int rc = ensure_blob(h, l)) return rc;
-    if (int rc = ensure_workspace(h, l.NP, l.npass)) return rc;
-    const int NP = (int)l.NP;
-    hipStream_t s = h->stream;
-
-    // ---- host preparation: header, scaled + padded sources, padded targets
-    std::vector<double> hdr(HDR_DOUBLES, 0.0);
-    hdr[0] = MAGIC; hdr[1] = (double)N; hdr[2] = (double)NP; hdr[3] = D; hdr[4] = O;
-    hdr[5] = constant_value; hdr[6] = noise_level; hdr[7] = alpha_jitter;
-    for (int d = 0; d < 3; ++d) hdr[8 + d] = (d < D) ? length_scale[n_ls == 1 ? 0 : d] : 1.0;
-    hdr[11] = n_ls; hdr[12] = l.npass; hdr[13] = kernel_type;
-    fill_params(h, hdr.data());
-    std::vector<double> xs((size_t)NP * 4, 0.0), y4((size_t)l.npass * NP * 4, 0.0);
-    for (int64_t i = 0; i < N; ++i) {
-        for (int d = 0; d < D; ++d) xs[(size_t)i * 4 + d] = X[i * D + d] * h->p.inv_ls[d];
-        for (int o = 0; o < O; ++o) y4[((size_t)(o / 4) * NP + i) * 4 + (o % 4)] = Y[i * O + o];
-    }
-    h->hostY.assign(Y, Y + (size_t)N * O);
-    HIPCHK(hipMemcpyAsync(h->blob, hdr.data(), HDR_DOUBLES * sizeof(double), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(h->dXs(), xs.data(), xs.size() * sizeof(double), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(h->dY4, y4.data(), y4.size() * sizeof(double), hipMemcpyHostToDevice, s));
-    HIPCHK(hipStreamSynchronize(s));   // host vectors go out of scope below
-
-    // ---- device pipeline
-    HIPCHK(hipEventRecord(h->ev[0], s));
-    HIPCHK(hipMemsetAsync(h->dinfo, 0, sizeof(int), s));
-    HIPCHK(hipMemsetAsync(h->dW, 0, (size_t)NP * NP * sizeof(double), s));
-    launch_gram(s, h->dXs(), (int)N, NP, kernel_type, constant_value, noise_level + alpha_jitter, h->dK);
-    if (Sigma) {      // K += Sigma: staged through dW (not in use until the factorisation starts)
-        HIPCHK(hipMemcpyAsync(h->dW, Sigma, (size_t)N * N * sizeof(double), hipMemcpyHostToDevice, s));
-        launch_add_lower(s, h->dK, h->dW, (int)N, NP);
-        HIPCHK(hipMemsetAsync(h->dW, 0, (size_t)NP * NP * sizeof(double), s));
-    }
-    HIPCHK(hipEventRecord(h->ev[1], s));
-    launch_potrf(s, h->dK, h->dW, NP, h->dinfo);
-    HIPCHK(hipEventRecord(h->ev[2], s));
-    launch_trinv(s, h->dK, h->dW, NP, h->dWf());
-    HIPCHK(hipEventRecord(h->ev[3], s));
-    for (int ps = 0; ps < l.npass; ++ps)
-        launch_alpha(s, h->dW, h->dY4 + (size_t)ps * NP * 4, (int)N, NP, h->dT4, h->dA4() + (size_t)ps * NP * 4, h->dWf());
-    HIPCHK(hipEventRecord(h->ev[4], s));
-    launch_pack_w(s, h->dW, (int)N, NP, h->dWf());
-    HIPCHK(hipEventRecord(h->ev[5], s));
-    HIPCHK(hipGetLastError());
-    int info = 0;
-    HIPCHK(hipMemcpyAsync(&info, h->dinfo, sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+static int read_fit_times(gpt_handle* h) {
     float ms = 0;
     for (int i = 1; i <= 5; ++i) {
         HIPCHK(hipEventElapsedTime(&ms, h->ev[i - 1], h->ev[i]));
@@ -337,57 +440,143 @@ static int fit_impl(gpt_handle* h, const double* X, const double* Y, int64_t N, 
     }
     HIPCHK(hipEventElapsedTime(&ms, h->ev[0], h->ev[5]));
     h->fit_ms[0] = ms;
+    return GPT_OK;
+}
+
+static int fit_impl(gpt_handle* h, const double* X, const double* Y, int64_t N, int D, int O,
+                    const double* length_scale, int n_ls, double constant_value, double noise_level,
+                    double alpha_jitter, int kernel_type, const double* Sigma) {
+    if (!h || !X || !Y || !length_scale) return fail(GPT_E_ARG, "gpt_fit: NULL argument");
+    if (kernel_type < GPT_KERNEL_RBF || kernel_type > GPT_KERNEL_MATERN52) return fail(GPT_E_ARG, "gpt_fit: unknown kernel_type");
+    if (int rc = check_geometry("gpt_fit", N, D, O, length_scale, n_ls)) return rc;
+    if (!(constant_value > 0.0) || !(noise_level >= 0.0) || !(alpha_jitter >= 0.0))
+        return fail(GPT_E_ARG, "gpt_fit: constant_value > 0, noise_level >= 0, alpha >= 0 required");
+    if (int rc = set_device(h)) return rc;
+    h->committed = false;
+    h->have_L = h->have_W = false;
+    const Layout l = make_layout(N, D, O, 1, h->dtype_next);
+    if (int rc = ensure_blob(h, l)) return rc;
+    if (int rc = ensure_workspace(h, l.NP, l.npass)) return rc;
+    const int NP = (int)l.NP;
+    hipStream_t s = h->stream;
+
+    // ---- host preparation: header, scaled + padded sources, padded targets
+    std::vector<double> hdr;
+    if (int rc = upload_sources(h, l, X, hdr, length_scale, n_ls, constant_value, noise_level, alpha_jitter, kernel_type)) return rc;
+    hdr[HDR_TASK_C] = constant_value;
+    std::vector<double> y4((size_t)l.npass * NP * 4, 0.0);
+    for (int64_t i = 0; i < N; ++i)
+        for (int o = 0; o < O; ++o) y4[((size_t)(o / 4) * NP + i) * 4 + (o % 4)] = Y[i * O + o];
+    h->hostY.assign(Y, Y + (size_t)N * O);
+    HIPCHK(hipMemcpyAsync(h->blob, hdr.data(), HDR_DOUBLES * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->dY4, y4.data(), y4.size() * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));   // host vectors go out of scope below
+
+    // ---- device pipeline
+    HIPCHK(hipEventRecord(h->ev[0], s));
+    if (int rc = factorise(h, N, NP, kernel_type, constant_value, noise_level + alpha_jitter, Sigma)) return rc;
+    for (int ps = 0; ps < l.npass; ++ps) {
+        double* a64 = h->dA64 + (size_t)ps * NP * 4;
+        launch_alpha(s, h->dW, h->dY4 + (size_t)ps * NP * 4, (int)N, NP, h->dT4, a64, h->dScr);
+        launch_store4(s, a64, NP, static_cast<unsigned char*>(h->dA4()) + (size_t)ps * NP * 4 * l.esz, l.dtype, 0, 0, 4, 1.0);
+    }
+    HIPCHK(hipEventRecord(h->ev[4], s));
+    launch_pack_w(s, h->dW, (int)N, NP, h->dWf(), l.dtype, 0, 1.0);
+    HIPCHK(hipMemsetAsync(static_cast<unsigned char*>(h->dWf()) + wf_elems(NP) * l.esz, 0, wf_overrun_elems() * l.esz, s));
+    HIPCHK(hipEventRecord(h->ev[5], s));
+    HIPCHK(hipGetLastError());
+    int info = 0;
+    HIPCHK(hipMemcpyAsync(&info, h->dinfo, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (int rc = read_fit_times(h)) return rc;
     if (info != 0) {
-        h->have_factor_ws = false;
         char buf[160];
         snprintf(buf, sizeof buf, "gpt_fit: kernel matrix is not positive definite (pivot %d <= 0)", info);
         return fail(GPT_E_NOT_PD, buf);
     }
     h->committed = true;
-    h->have_factor_ws = true;
+    h->have_L = h->have_W = true;
     return GPT_OK;
 }
 
-namespace {
-// grow-only scratch of the variance kernel; reallocation waits for work that may still use the old buffers
-int ensure_var_scratch(gpt_handle* h, int64_t M, int ncomp) {
+int gpt_fit_svgp(gpt_handle* h, const double* Z, const double* y, const double* Sigma, int64_t N, int D, int T,
+                 const double* length_scale, int n_ls, const double* outputscale, double jitter, int dtype) {
+    if (!h || !Z || !y || !Sigma || !length_scale || !outputscale) return fail(GPT_E_ARG, "gpt_fit_svgp: NULL argument");
+    if (T < 1 || T > MAX_TASKS) return fail(GPT_E_ARG, "gpt_fit_svgp: number of tasks must be 1..32");
+    if (dtype != GPT_F64 && dtype != GPT_F32) return fail(GPT_E_ARG, "gpt_fit_svgp: dtype must be GPT_F64 or GPT_F32");
+    if (int rc = check_geometry("gpt_fit_svgp", N, D, T, length_scale, n_ls)) return rc;
+    for (int t = 0; t < T; ++t)
+        if (!(outputscale[t] > 0.0)) return fail(GPT_E_ARG, "gpt_fit_svgp: outputscale must be > 0");
+    if (!(jitter >= 0.0)) return fail(GPT_E_ARG, "gpt_fit_svgp: jitter >= 0 required");
+    if (int rc = set_device(h)) return rc;
+    h->committed = false;
+    h->have_L = h->have_W = false;
+    const Layout l = make_layout(N, D, T, T, dtype);
+    if (int rc = ensure_blob(h, l)) return rc;
+    if (int rc = ensure_workspace(h, l.NP, l.npass)) return rc;
+    const int NP = (int)l.NP;
     hipStream_t s = h->stream;
-    const size_t need = var_slab_doubles(M, ncomp);
-    if (need > h->slab_cap) {
-        HIPCHK(hipStreamSynchronize(s));
-        if (h->slab) (void)hipFree(h->slab);
-        h->slab = nullptr; h->slab_cap = 0;
-        HIPCHK(hipMalloc(&h->slab, need * sizeof(double)));
-        h->slab_cap = need;
+    // the kernel columns are generated WITHOUT the outputscale (c = 1): it is folded into each task's inverse factor
+    // and alpha, so that all tasks share one B operand
+    std::vector<double> hdr;
+    if (int rc = upload_sources(h, l, Z, hdr, length_scale, n_ls, 1.0, 0.0, jitter, GPT_KERNEL_RBF)) return rc;
+    for (int t = 0; t < T; ++t) hdr[HDR_TASK_C + t] = outputscale[t];
+    HIPCHK(hipMemcpyAsync(h->blob, hdr.data(), HDR_DOUBLES * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(h->dA4(), 0, (size_t)l.npass * NP * 4 * l.esz, s));
+    HIPCHK(hipMemsetAsync(h->dA64, 0, (size_t)l.npass * NP * 4 * sizeof(double), s));
+    HIPCHK(hipStreamSynchronize(s));
+    h->hostY.clear();
+    std::vector<double> y4((size_t)NP * 4);
+    HIPCHK(hipEventRecord(h->ev[0], s));
+    int info = 0, bad_task = -1;
+    for (int t = 0; t < T && info == 0; ++t) {
+        std::fill(y4.begin(), y4.end(), 0.0);
+        for (int64_t i = 0; i < N; ++i) y4[(size_t)i * 4] = y[(size_t)t * N + i];
+        HIPCHK(hipMemcpyAsync(h->dY4, y4.data(), y4.size() * sizeof(double), hipMemcpyHostToDevice, s));
+        if (int rc = factorise(h, N, NP, GPT_KERNEL_RBF, outputscale[t], jitter, Sigma + (size_t)t * N * N)) return rc;
+        launch_alpha(s, h->dW, h->dY4, (int)N, NP, h->dT4, h->dTa, h->dScr);
+        const size_t col_off = (size_t)(t / 4) * NP * 4;
+        launch_store4(s, h->dTa, NP, h->dA64 + col_off, DT_F64, 0, t % 4, 1, 1.0);
+        launch_store4(s, h->dTa, NP, static_cast<unsigned char*>(h->dA4()) + col_off * l.esz, l.dtype, 0, t % 4, 1, outputscale[t]);
+        launch_pack_w(s, h->dW, (int)N, NP, h->dWf(), l.dtype, t, outputscale[t]);
+        HIPCHK(hipMemcpyAsync(&info, h->dinfo, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));           // y4 is reused; the pivot check of this task
+        if (info != 0) bad_task = t;
     }
-    const size_t needb = var_bscratch_doubles(h->p.NP);
-    if (needb > h->bscratch_cap) {
-        HIPCHK(hipStreamSynchronize(s));
-        if (h->bscratch) (void)hipFree(h->bscratch);
-        h->bscratch = nullptr; h->bscratch_cap = 0;
-        HIPCHK(hipMalloc(&h->bscratch, needb * sizeof(double)));
-        h->bscratch_cap = needb;
+    HIPCHK(hipMemsetAsync(static_cast<unsigned char*>(h->dWf()) + (size_t)T * wf_elems(NP) * l.esz, 0, wf_overrun_elems() * l.esz, s));
+    HIPCHK(hipEventRecord(h->ev[4], s));
+    HIPCHK(hipEventRecord(h->ev[5], s));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s));
+    if (int rc = read_fit_times(h)) return rc;
+    if (info != 0) {
+        char buf[200];
+        snprintf(buf, sizeof buf, "gpt_fit_svgp: K_uu + Sigma of task %d is not positive definite (pivot %d <= 0)", bad_task, info);
+        return fail(GPT_E_NOT_PD, buf);
     }
+    h->committed = true;           // dK / dW hold the LAST task's factors only: no export, covariance or LML for this model
     return GPT_OK;
 }
-}  // namespace
 
 int gpt_reserve(gpt_handle* h, int64_t M, int jacobian_variance) {
     if (!h) return fail(GPT_E_ARG, "gpt_reserve: NULL handle");
     if (!h->committed) return fail(GPT_E_STATE, "gpt_reserve: model is not fitted");
     if (M < 0) return fail(GPT_E_ARG, "gpt_reserve: bad query count");
     if (int rc = set_device(h)) return rc;
-    return M == 0 ? GPT_OK : ensure_var_scratch(h, M, jacobian_variance ? 4 : 1);
+    if (M == 0) return GPT_OK;
+    HIPCHK(var_prepare(h->vws, h->stream, h->p, M, jacobian_variance ? 4 : 1));
+    return GPT_OK;
 }
 
-int gpt_predict_all_dev(gpt_handle* h, const double* Xq, int64_t M, double* mean, double* var,
-                        double* J, double* Jvar, double* dvar) {
+int gpt_predict_all_dev(gpt_handle* h, const void* Xq, int64_t M, void* mean, void* var,
+                        void* J, void* Jvar, void* dvar) {
     if (!h) return fail(GPT_E_ARG, "gpt_predict_all_dev: NULL handle");
     if (!h->committed) return fail(GPT_E_STATE, "predict: model is not fitted");
     if (M < 0 || (M > 0 && !Xq)) return fail(GPT_E_ARG, "predict: bad query buffer");
     if (M == 0) return GPT_OK;
     if ((J || Jvar || dvar) && h->p.ktype != GPT_KERNEL_RBF)
         return fail(GPT_E_ARG, "derivative / Jacobian variance / d variance are defined for the RBF kernel only");
+    if (dvar && h->p.ntask != 1) return fail(GPT_E_ARG, "d variance is not defined for the multi-task (SVGP) model");
     if (int rc = set_device(h)) return rc;
     hipStream_t s = h->stream;
     const bool prof = h->profiling;
@@ -400,37 +589,46 @@ int gpt_predict_all_dev(gpt_handle* h, const double* Xq, int64_t M, double* mean
     }
     if (h->pred_var) {
         const int ncomp = dvar ? 4 : (Jvar ? (var ? 4 : 3) : 1);     // 3: Jacobian variance alone (no k* column)
-        if (int rc = ensure_var_scratch(h, M, ncomp)) return rc;
+        HIPCHK(var_prepare(h->vws, s, h->p, M, ncomp));
         if (prof) HIPCHK(hipEventRecord(h->pev[2], s));
-        if (ncomp == 1) launch_var(s, h->p, h->dXs(), h->dWf(), Xq, M, 1, var, nullptr, nullptr, h->slab, h->bscratch);
-        else launch_var(s, h->p, h->dXs(), h->dWf(), Xq, M, ncomp, var, Jvar, dvar, h->slab, h->bscratch);
+        launch_var(s, h->p, h->vws, h->dXs(), h->dWf(), Xq, M, ncomp, var, ncomp == 1 ? nullptr : Jvar, ncomp == 1 ? nullptr : dvar, h->dHdr());
         if (prof) HIPCHK(hipEventRecord(h->pev[3], s));
     }
     HIPCHK(hipGetLastError());
     return GPT_OK;
 }
 
-int gpt_predict_all(gpt_handle* h, const double* Xq, int64_t M, double* mean, double* var,
-                    double* J, double* Jvar, double* dvar) {
+int gpt_predict_all(gpt_handle* h, const void* Xq_, int64_t M, void* mean_, void* var_,
+                    void* J_, void* Jvar_, void* dvar_) {
     if (!h) return fail(GPT_E_ARG, "gpt_predict_all: NULL handle");
     if (!h->committed) return fail(GPT_E_STATE, "predict: model is not fitted");
-    if (M < 0 || (M > 0 && !Xq)) return fail(GPT_E_ARG, "predict: bad query buffer");
+    if (M < 0 || (M > 0 && !Xq_)) return fail(GPT_E_ARG, "predict: bad query buffer");
     if (M == 0) return GPT_OK;
     if (int rc = set_device(h)) return rc;
-    const int D = h->p.D, O = h->p.O;
+    const size_t esz = h->lay.esz;
+    const size_t D = h->p.D, O = h->p.O, NT = h->p.ntask;
+    const unsigned char* Xq = static_cast<const unsigned char*>(Xq_);
+    unsigned char *mean = static_cast<unsigned char*>(mean_), *var = static_cast<unsigned char*>(var_), *J = static_cast<unsigned char*>(J_),
+                  *Jvar = static_cast<unsigned char*>(Jvar_), *dvar = static_cast<unsigned char*>(dvar_);
     const int64_t cap = M < HOST_CHUNK ? M : HOST_CHUNK;
-    if (int rc = ensure_staging(h, cap, D, O)) return rc;
-    hipStream_t s = h->stream, cs = h->copy_stream;
     const int64_t nchunks = (M + cap - 1) / cap;
+    // elements per query of each staged array
+    const size_t per[ST_COUNT] = {D, O, NT, O * D, NT * D, D};
+    void* const want[ST_COUNT] = {(void*)Xq, mean, var, J, Jvar, dvar};
+    for (int b = 0; b < (nchunks > 1 ? 2 : 1); ++b)
+        for (int i = 0; i < ST_COUNT; ++i)
+            if (want[i]) { if (int rc = ensure_stage(h, b, i, (size_t)cap * per[i] * esz)) return rc; }
+    if (int rc = ensure_copy_stream(h)) return rc;
+    hipStream_t s = h->stream, cs = h->copy_stream;
     // chunk i computes on `s` in staging set i & 1; its outputs leave on `cs` while chunk i + 1 computes
     auto enqueue = [&](int64_t i) -> int {
         const int b = (int)(i & 1);
         const int64_t off = i * cap, m = (M - off) < cap ? (M - off) : cap;
         gpt_handle::Staging& t = h->st[b];
         if (i >= 2) HIPCHK(hipStreamWaitEvent(s, h->ev_copied[b], 0));          // set b is free again
-        HIPCHK(hipMemcpyAsync(t.q, Xq + off * D, (size_t)m * D * sizeof(double), hipMemcpyHostToDevice, s));
-        if (int rc = gpt_predict_all_dev(h, t.q, m, mean ? t.mean : nullptr, var ? t.var : nullptr, J ? t.J : nullptr,
-                                         Jvar ? t.Jvar : nullptr, dvar ? t.dvar : nullptr))
+        HIPCHK(hipMemcpyAsync(t.buf[ST_Q], Xq + (size_t)off * D * esz, (size_t)m * D * esz, hipMemcpyHostToDevice, s));
+        if (int rc = gpt_predict_all_dev(h, t.buf[ST_Q], m, mean ? t.buf[ST_MEAN] : nullptr, var ? t.buf[ST_VAR] : nullptr,
+                                         J ? t.buf[ST_J] : nullptr, Jvar ? t.buf[ST_JVAR] : nullptr, dvar ? t.buf[ST_DVAR] : nullptr))
             return rc;
         HIPCHK(hipEventRecord(h->ev_done[b], s));
         return GPT_OK;
@@ -440,14 +638,13 @@ int gpt_predict_all(gpt_handle* h, const double* Xq, int64_t M, double* mean, do
         const int64_t off = i * cap, m = (M - off) < cap ? (M - off) : cap;
         const gpt_handle::Staging& t = h->st[b];
         HIPCHK(hipStreamWaitEvent(cs, h->ev_done[b], 0));
-        if (mean) HIPCHK(hipMemcpyAsync(mean + off * O, t.mean, (size_t)m * O * sizeof(double), hipMemcpyDeviceToHost, cs));
-        if (var) HIPCHK(hipMemcpyAsync(var + off, t.var, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, cs));
-        if (J) HIPCHK(hipMemcpyAsync(J + off * O * D, t.J, (size_t)m * O * D * sizeof(double), hipMemcpyDeviceToHost, cs));
-        if (Jvar) HIPCHK(hipMemcpyAsync(Jvar + off * D, t.Jvar, (size_t)m * D * sizeof(double), hipMemcpyDeviceToHost, cs));
+        unsigned char* const dst[ST_COUNT] = {nullptr, mean, var, J, Jvar, nullptr};
+        for (int k = ST_MEAN; k <= ST_JVAR; ++k)
+            if (dst[k]) HIPCHK(hipMemcpyAsync(dst[k] + (size_t)off * per[k] * esz, t.buf[k], (size_t)m * per[k] * esz, hipMemcpyDeviceToHost, cs));
         if (dvar)
-            for (int d = 0; d < D; ++d)   // device chunk is (D, m); host result is (D, M)
-                HIPCHK(hipMemcpyAsync(dvar + (size_t)d * M + off, t.dvar + (size_t)d * m, (size_t)m * sizeof(double),
-                                      hipMemcpyDeviceToHost, cs));
+            for (size_t d = 0; d < D; ++d)   // device chunk is (D, m); host result is (D, M)
+                HIPCHK(hipMemcpyAsync(dvar + (d * (size_t)M + (size_t)off) * esz, static_cast<unsigned char*>(t.buf[ST_DVAR]) + d * (size_t)m * esz,
+                                      (size_t)m * esz, hipMemcpyDeviceToHost, cs));
         HIPCHK(hipEventRecord(h->ev_copied[b], cs));
         return GPT_OK;
     };
@@ -461,16 +658,36 @@ int gpt_predict_all(gpt_handle* h, const double* Xq, int64_t M, double* mean, do
     return GPT_OK;
 }
 
-int gpt_predict(gpt_handle* h, const double* Xq, int64_t M, double* mean, double* var) {
+int gpt_predict(gpt_handle* h, const void* Xq, int64_t M, void* mean, void* var) {
     return gpt_predict_all(h, Xq, M, mean, var, nullptr, nullptr, nullptr);
 }
 
-int gpt_derivative(gpt_handle* h, const double* Xq, int64_t M, double* J, double* Jvar) {
+int gpt_derivative(gpt_handle* h, const void* Xq, int64_t M, void* J, void* Jvar) {
     return gpt_predict_all(h, Xq, M, nullptr, nullptr, J, Jvar, nullptr);
 }
 
-int gpt_dvariance(gpt_handle* h, const double* Xq, int64_t M, double* g) {
+int gpt_dvariance(gpt_handle* h, const void* Xq, int64_t M, void* g) {
     return gpt_predict_all(h, Xq, M, nullptr, nullptr, nullptr, nullptr, g);
+}
+
+// alpha as (N,O) fp64 host array: from the fp64 workspace when this handle ran the fit, else converted from the blob
+static int fetch_alpha(gpt_handle* h, std::vector<double>& a4) {
+    const int64_t NP = h->p.NP;
+    const size_t n = (size_t)h->lay.npass * NP * 4;
+    a4.resize(n);
+    if (h->have_W) {
+        HIPCHK(hipMemcpyAsync(a4.data(), h->dA64, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    } else if (h->lay.dtype == DT_F32) {
+        std::vector<float> af(n);
+        HIPCHK(hipMemcpyAsync(af.data(), h->dA4(), n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        for (size_t i = 0; i < n; ++i) a4[i] = af[i];
+    } else {
+        HIPCHK(hipMemcpyAsync(a4.data(), h->dA4(), n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return GPT_OK;
 }
 
 int gpt_export(gpt_handle* h, double* L, double* alpha) {
@@ -481,15 +698,16 @@ int gpt_export(gpt_handle* h, double* L, double* alpha) {
     const int O = h->p.O;
     HIPCHK(hipStreamSynchronize(h->stream));
     if (L) {
-        if (!h->have_factor_ws) return fail(GPT_E_STATE, "gpt_export: L is only available on the rank that ran gpt_fit");
+        if (!h->have_L) return fail(GPT_E_STATE, "gpt_export: L is only available on the handle that ran gpt_fit (and before gpt_lml_gradient)");
         HIPCHK(hipMemcpy2D(L, (size_t)N * sizeof(double), h->dK, (size_t)NP * sizeof(double), (size_t)N * sizeof(double),
                            (size_t)N, hipMemcpyDeviceToHost));
         for (int64_t i = 0; i < N; ++i)
             for (int64_t j = i + 1; j < N; ++j) L[i * N + j] = 0.0;
     }
     if (alpha) {
-        std::vector<double> a4((size_t)h->lay.npass * NP * 4);
-        HIPCHK(hipMemcpy(a4.data(), h->dA4(), a4.size() * sizeof(double), hipMemcpyDeviceToHost));
+        // (for the multi-task model: alpha of task t in column t, times its outputscale when read back from the blob)
+        std::vector<double> a4;
+        if (int rc = fetch_alpha(h, a4)) return rc;
         for (int64_t i = 0; i < N; ++i)
             for (int o = 0; o < O; ++o) alpha[i * O + o] = a4[((size_t)(o / 4) * NP + i) * 4 + (o % 4)];
     }
@@ -498,7 +716,7 @@ int gpt_export(gpt_handle* h, double* L, double* alpha) {
 
 int gpt_export_inverse_factor(gpt_handle* h, double* W) {
     if (!h || !W) return fail(GPT_E_ARG, "gpt_export_inverse_factor: NULL argument");
-    if (!h->committed || !h->have_factor_ws) return fail(GPT_E_STATE, "gpt_export_inverse_factor: no factor on this handle");
+    if (!h->committed || !h->have_W) return fail(GPT_E_STATE, "gpt_export_inverse_factor: no factor on this handle");
     if (int rc = set_device(h)) return rc;
     const int64_t N = h->p.N, NP = h->p.NP;
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -509,16 +727,15 @@ int gpt_export_inverse_factor(gpt_handle* h, double* W) {
 
 int gpt_lml(gpt_handle* h, double* lml) {
     if (!h || !lml) return fail(GPT_E_ARG, "gpt_lml: NULL argument");
-    if (!h->committed || !h->have_factor_ws) return fail(GPT_E_STATE, "gpt_lml: needs the handle that ran gpt_fit");
+    if (!h->committed || !h->have_L || !h->have_W) return fail(GPT_E_STATE, "gpt_lml: needs the handle that ran gpt_fit");
     if (int rc = set_device(h)) return rc;
     const int64_t N = h->p.N, NP = h->p.NP;
     const int O = h->p.O;
     launch_logdet(h->stream, h->dK, (int)N, (int)NP, h->dscal);
     double logdet = 0;
     HIPCHK(hipMemcpyAsync(&logdet, h->dscal, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    std::vector<double> a4((size_t)h->lay.npass * NP * 4);
-    HIPCHK(hipMemcpyAsync(a4.data(), h->dA4(), a4.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    std::vector<double> a4;
+    if (int rc = fetch_alpha(h, a4)) return rc;
     double total = 0;
     for (int o = 0; o < O; ++o) {
         double ya = 0;
@@ -532,7 +749,8 @@ int gpt_lml(gpt_handle* h, double* lml) {
 int gpt_predict_cov(gpt_handle* h, const double* Xq, int64_t M, double* mean, double* cov) {
     if (!h || !cov) return fail(GPT_E_ARG, "gpt_predict_cov: NULL argument");
     if (!h->committed) return fail(GPT_E_STATE, "predict: model is not fitted");
-    if (!h->dW || h->ws_np != h->p.NP) return fail(GPT_E_STATE, "gpt_predict_cov: needs the handle that ran gpt_fit");
+    if (!h->have_W) return fail(GPT_E_STATE, "gpt_predict_cov: needs the handle that ran gpt_fit for this model");
+    if (h->lay.dtype != DT_F64) return fail(GPT_E_STATE, "gpt_predict_cov: fp64 models only");
     if (M < 0 || (M > 0 && !Xq)) return fail(GPT_E_ARG, "predict: bad query buffer");
     if (M > 16384) return fail(GPT_E_ARG, "gpt_predict_cov: M x M covariance limited to M <= 16384");
     if (M == 0) return GPT_OK;
@@ -542,44 +760,50 @@ int gpt_predict_cov(gpt_handle* h, const double* Xq, int64_t M, double* mean, do
     const int64_t NP = h->p.NP;
     const int Mp = (int)((M + 127) / 128 * 128);
     hipStream_t s = h->stream;
-    double *dq = nullptr, *KsT = nullptr, *V = nullptr, *VtV = nullptr, *dcov = nullptr;
-    auto cleanup = [&]() { for (double* ptr : {dq, KsT, V, VtV, dcov}) if (ptr) (void)hipFree(ptr); };
-    hipError_t e = hipSuccess;
-    if ((e = hipMalloc(&dq, (size_t)M * D * sizeof(double))) == hipSuccess &&
-        (e = hipMalloc(&KsT, (size_t)NP * Mp * sizeof(double))) == hipSuccess &&
-        (e = hipMalloc(&V, (size_t)NP * Mp * sizeof(double))) == hipSuccess &&
-        (e = hipMalloc(&VtV, (size_t)Mp * Mp * sizeof(double))) == hipSuccess &&
-        (e = hipMalloc(&dcov, (size_t)M * M * sizeof(double))) == hipSuccess &&
-        (e = hipMemcpyAsync(dq, Xq, (size_t)M * D * sizeof(double), hipMemcpyHostToDevice, s)) == hipSuccess) {
-        launch_cov(s, h->p, h->dXs(), h->dW, dq, M, Mp, KsT, V, VtV, dcov);
-        e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync(cov, dcov, (size_t)M * M * sizeof(double), hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
+    // one grow-only scratch: [dq | KsT | V | VtV | dcov]
+    auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t b_q = al((size_t)M * D * sizeof(double)), b_k = al((size_t)NP * Mp * sizeof(double)),
+                 b_vv = al((size_t)Mp * Mp * sizeof(double)), b_c = al((size_t)M * M * sizeof(double));
+    const size_t need = b_q + 2 * b_k + b_vv + b_c;
+    if (need > h->cov_cap) {
+        HIPCHK(hipStreamSynchronize(s));
+        if (h->cov_buf) (void)hipFree(h->cov_buf);
+        h->cov_buf = nullptr; h->cov_cap = 0;
+        HIPCHK(hipMalloc(&h->cov_buf, need));
+        h->cov_cap = need;
     }
-    cleanup();
-    if (e != hipSuccess) return fail(GPT_E_HIP, std::string("gpt_predict_cov: ") + hipGetErrorString(e));
+    double* dq = reinterpret_cast<double*>(h->cov_buf);
+    double* KsT = reinterpret_cast<double*>(h->cov_buf + b_q);
+    double* V = reinterpret_cast<double*>(h->cov_buf + b_q + b_k);
+    double* VtV = reinterpret_cast<double*>(h->cov_buf + b_q + 2 * b_k);
+    double* dcov = reinterpret_cast<double*>(h->cov_buf + b_q + 2 * b_k + b_vv);
+    HIPCHK(hipMemcpyAsync(dq, Xq, (size_t)M * D * sizeof(double), hipMemcpyHostToDevice, s));
+    launch_cov(s, h->p, h->dXs64, h->dW, dq, M, Mp, KsT, V, VtV, dcov);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(cov, dcov, (size_t)M * M * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
     return GPT_OK;
 }
 
 int gpt_lml_gradient(gpt_handle* h, double* lml, double* grad) {
     if (!h || !lml || !grad) return fail(GPT_E_ARG, "gpt_lml_gradient: NULL argument");
-    if (!h->committed || !h->have_factor_ws) return fail(GPT_E_STATE, "gpt_lml_gradient: needs the handle that ran gpt_fit");
+    if (!h->committed || !h->have_L || !h->have_W) return fail(GPT_E_STATE, "gpt_lml_gradient: needs the handle that ran gpt_fit");
     if (int rc = gpt_lml(h, lml)) return rc;                    // uses diag(L) in dK before it is overwritten
     const int64_t N = h->p.N, NP = h->p.NP;
     const int D = h->p.D, O = h->p.O;
     hipStream_t s = h->stream;
-    // K^-1 (lower) into dK, partial sums into the (currently idle) slab/partial scratch
+    // K^-1 (lower) into dK, per-tile partial sums into their own scratch
     const size_t need = (size_t)(NP / 64) * (NP / 64) * 8;
-    if (need > h->slab_cap) {
+    if (need > h->lml_partial_cap) {
         HIPCHK(hipStreamSynchronize(s));
-        if (h->slab) (void)hipFree(h->slab);
-        h->slab = nullptr; h->slab_cap = 0;
-        HIPCHK(hipMalloc(&h->slab, need * sizeof(double)));
-        h->slab_cap = need;
+        if (h->lml_partial) (void)hipFree(h->lml_partial);
+        h->lml_partial = nullptr; h->lml_partial_cap = 0;
+        HIPCHK(hipMalloc(&h->lml_partial, need * sizeof(double)));
+        h->lml_partial_cap = need;
     }
-    h->have_factor_ws = false;                                   // L is gone: gpt_export(L) needs a new gpt_fit
+    h->have_L = false;                                           // L is gone: gpt_export(L) needs a new gpt_fit (W stays valid)
     launch_kinv(s, h->dW, (int)NP, h->dK);
-    launch_lml_terms(s, h->dXs(), h->dA4(), h->lay.npass, h->dK, (int)N, (int)NP, O, h->p.ktype, h->p.c, h->slab, h->dscal);
+    launch_lml_terms(s, h->dXs64, h->dA64, h->lay.npass, h->dK, (int)N, (int)NP, O, h->p.ktype, h->p.c, h->lml_partial, h->dscal);
     HIPCHK(hipGetLastError());
     double S[5];
     HIPCHK(hipMemcpyAsync(S, h->dscal, sizeof S, hipMemcpyDeviceToHost, s));
@@ -601,20 +825,25 @@ int gpt_factor_blob(gpt_handle* h, void** dev_ptr, size_t* bytes) {
     if (!h || !dev_ptr || !bytes) return fail(GPT_E_ARG, "gpt_factor_blob: NULL argument");
     if (!h->blob || !h->have_layout) return fail(GPT_E_STATE, "gpt_factor_blob: no model storage");
     *dev_ptr = h->blob;
-    *bytes = h->lay.total * sizeof(double);
+    *bytes = h->lay.total;
+    return GPT_OK;
+}
+
+int gpt_factor_alloc_model(gpt_handle* h, int64_t N, int D, int O, int n_tasks, int dtype, void** dev_ptr, size_t* bytes) {
+    if (!h || !dev_ptr || !bytes) return fail(GPT_E_ARG, "gpt_factor_alloc: NULL argument");
+    if (N < 1 || D < 1 || D > 3 || O < 1 || n_tasks < 1 || n_tasks > MAX_TASKS || (dtype != GPT_F64 && dtype != GPT_F32))
+        return fail(GPT_E_ARG, "gpt_factor_alloc: bad geometry");
+    if (int rc = set_device(h)) return rc;
+    h->committed = false;
+    h->have_L = h->have_W = false;
+    if (int rc = ensure_blob(h, make_layout(N, D, O, n_tasks, dtype))) return rc;
+    *dev_ptr = h->blob;
+    *bytes = h->lay.total;
     return GPT_OK;
 }
 
 int gpt_factor_alloc(gpt_handle* h, int64_t N, int D, int O, void** dev_ptr, size_t* bytes) {
-    if (!h || !dev_ptr || !bytes) return fail(GPT_E_ARG, "gpt_factor_alloc: NULL argument");
-    if (N < 1 || D < 1 || D > 3 || O < 1) return fail(GPT_E_ARG, "gpt_factor_alloc: bad geometry");
-    if (int rc = set_device(h)) return rc;
-    h->committed = false;
-    h->have_factor_ws = false;
-    if (int rc = ensure_blob(h, make_layout(N, D, O))) return rc;
-    *dev_ptr = h->blob;
-    *bytes = h->lay.total * sizeof(double);
-    return GPT_OK;
+    return gpt_factor_alloc_model(h, N, D, O, 1, GPT_F64, dev_ptr, bytes);
 }
 
 int gpt_factor_commit(gpt_handle* h) {
@@ -625,7 +854,8 @@ int gpt_factor_commit(gpt_handle* h) {
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(hdr, h->blob, sizeof hdr, hipMemcpyDeviceToHost));
     if (hdr[0] != MAGIC) return fail(GPT_E_STATE, "gpt_factor_commit: blob has no model header (broadcast missing?)");
-    if ((int64_t)hdr[1] != h->lay.N || (int)hdr[3] != h->lay.D || (int)hdr[4] != h->lay.O || (int64_t)hdr[2] != h->lay.NP)
+    if ((int64_t)hdr[1] != h->lay.N || (int)hdr[3] != h->lay.D || (int)hdr[4] != h->lay.O || (int64_t)hdr[2] != h->lay.NP ||
+        (int)hdr[14] != h->lay.ntask || (int)hdr[15] != h->lay.dtype)
         return fail(GPT_E_STATE, "gpt_factor_commit: header geometry differs from gpt_factor_alloc");
     fill_params(h, hdr);
     h->committed = true;
@@ -639,6 +869,14 @@ int gpt_info(gpt_handle* h, int64_t* N, int* D, int* O, int64_t* N_padded) {
     if (D) *D = h->p.D;
     if (O) *O = h->p.O;
     if (N_padded) *N_padded = h->p.NP;
+    return GPT_OK;
+}
+
+int gpt_model_info(gpt_handle* h, int* n_tasks, int* dtype) {
+    if (!h) return fail(GPT_E_ARG, "gpt_model_info: NULL handle");
+    if (!h->committed) return fail(GPT_E_STATE, "gpt_model_info: model is not fitted");
+    if (n_tasks) *n_tasks = h->p.ntask;
+    if (dtype) *dtype = h->p.dtype;
     return GPT_OK;
 }
 
@@ -670,6 +908,19 @@ int gpt_predict_timings(gpt_handle* h, double* ms_out) {
 int gpt_fit_timings(gpt_handle* h, double* ms_out, int n) {
     if (!h || !ms_out) return fail(GPT_E_ARG, "gpt_fit_timings: NULL argument");
     for (int i = 0; i < n && i < 6; ++i) ms_out[i] = h->fit_ms[i];
+    return GPT_OK;
+}
+
+int gpt_debug_var_plan(int64_t n_columns, int n_iblocks, int n_tasks, int n_workgroups, int order, int64_t* counts,
+                       int* item_begin, int* items, int* fin, int* splits) {
+    if (n_columns < 0 || n_iblocks < 1 || n_tasks < 1 || n_workgroups < 1 || !counts) return fail(GPT_E_ARG, "gpt_debug_var_plan: bad argument");
+    const VarPlanHost pl = build_var_plan(n_columns, n_iblocks, n_tasks, n_workgroups, order);
+    counts[0] = (int64_t)pl.items.size(); counts[1] = (int64_t)pl.splits.size(); counts[2] = pl.n_slots; counts[3] = pl.n_vslots;
+    counts[4] = pl.d.ncb; counts[5] = pl.d.nfull; counts[6] = (int64_t)pl.fin.size() / 2; counts[7] = pl.order;
+    if (item_begin) memcpy(item_begin, pl.item_begin.data(), pl.item_begin.size() * sizeof(int));
+    if (items && !pl.items.empty()) memcpy(items, pl.items.data(), pl.items.size() * sizeof(VarItem));
+    if (fin && !pl.fin.empty()) memcpy(fin, pl.fin.data(), pl.fin.size() * sizeof(int));
+    if (splits && !pl.splits.empty()) memcpy(splits, pl.splits.data(), pl.splits.size() * sizeof(VarSplit));
     return GPT_OK;
 }
 

@@ -1,13 +1,21 @@
 // Shared declarations of the gfx950 GP-transportation library (internal header).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdint>
 #include <cstddef>
 
 namespace gpt {
 
+#if defined(__clang__)      // device code only (the sanitizer build of the host orchestration is compiled by g++)
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+#endif
+
+// Element type of the prediction side of a model (the factorisation is always fp64).
+constexpr int DT_F64 = 0, DT_F32 = 1;
 
 // ---- geometry --------------------------------------------------------------------------
 // N is padded to NP = multiple of PAD_N so that every blocked kernel sees whole tiles.
@@ -23,6 +31,19 @@ constexpr size_t WT_TILE_DOUBLES = (size_t)WT * WT;           // doubles per til
 // Cholesky panel width / diagonal block size.
 constexpr int NB = 64;
 
+// Per-device one-time setup (hipFuncSetAttribute opt-ins, CU counts): a process may hold handles on several devices
+// (gpt_create takes a device), so "done once" has to mean once per device, not once per process.
+constexpr int MAX_DEVICES = 64;
+inline int current_device() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= MAX_DEVICES) d = 0;
+    return d;
+}
+struct PerDeviceOnce {
+    std::atomic<bool> done[MAX_DEVICES] = {};
+    bool first() { return !done[current_device()].exchange(true); }      // true exactly once per device
+};
+
 // Model parameters passed by value to the prediction kernels.
 struct KernelParams {
     double c;            // constant_value (prior variance)
@@ -34,6 +55,8 @@ struct KernelParams {
     int N;               // source points
     int NP;              // padded source points
     int ktype;           // 0 RBF, 1/2/3 Matern nu = 1/2, 3/2, 5/2 (gpt_exp.h)
+    int ntask;           // stacked inverse factors (1: exact GP; T: SVGP exact conversion, one per task)
+    int dtype;           // DT_F64 / DT_F32: element type of Xs, A4, Wf, queries and outputs
 };
 
 // ---- launchers (defined in the .hip files) --------------------------------------------
@@ -44,24 +67,39 @@ void launch_potrf(hipStream_t s, double* K, double* W, int NP, int* info);
 void launch_trinv(hipStream_t s, const double* L, double* W, int NP, double* scratch /* >= NP*NP/4 doubles */);
 void launch_alpha(hipStream_t s, const double* W, const double* Y4, int N, int NP, double* tmp4, double* A4,
                   double* scratch /* >= (NP/512)*NP*4 doubles */);
-void launch_pack_w(hipStream_t s, const double* W, int N, int NP, double* Wf);
+// W (row-major fp64, lower) * scale -> tile set `task` of the fragment-ordered stream Wf (element type dtype)
+void launch_pack_w(hipStream_t s, const double* W, int N, int NP, void* Wf, int dtype, int task, double scale);
+// fp64 [rows][4] image -> element type dtype, `ncol` columns starting at dst column `col0`, times scale
+void launch_store4(hipStream_t s, const double* src4, int rows, void* dst4, int dtype, int src_col0, int dst_col0, int ncol, double scale);
 void launch_logdet(hipStream_t s, const double* K, int N, int NP, double* out);
 void launch_kinv(hipStream_t s, const double* W, int NP, double* Kout);
 void launch_cov(hipStream_t s, const KernelParams& p, const double* Xs, const double* W, const double* Xq_dev, int64_t M,
                 int Mp, double* KsT /* NP*Mp */, double* V /* NP*Mp */, double* VtV /* Mp*Mp */, double* cov_dev /* M*M */);
 void launch_lml_terms(hipStream_t s, const double* Xs, const double* A4, int npass, const double* Kinv, int N, int NP,
                       int O, int ktype, double c, double* partial /* (NP/64)^2*8 doubles */, double* out /* 5 doubles */);
-// predict
-void launch_mean_jac(hipStream_t s, const KernelParams& p, const double* Xs, const double* A4,
-                     const double* Xq, int64_t M, double* mean, double* J);
-// `slab`: scratch of var_slab_doubles(M, ncomp) doubles (per-piece partial column sums);
-// `bscratch`: var_bscratch_doubles(NP) doubles (per-workgroup image of the generated B fragments)
-void launch_var(hipStream_t s, const KernelParams& p, const double* Xs, const double* Wf,
-                const double* Xq, int64_t M, int ncomp, double* var, double* Jvar, double* dvar, double* slab,
-                double* bscratch);
-size_t var_slab_doubles(int64_t M, int ncomp);
-size_t var_bscratch_doubles(int NP);
+// predict (buffers in the model's element type)
+void launch_mean_jac(hipStream_t s, const KernelParams& p, const void* Xs, const void* A4,
+                     const void* Xq, int64_t M, void* mean, void* J);
 
-size_t wf_doubles(int NP);
+// Scratch of the variance kernel, owned by a handle (grow-only) and the cached work plan of the last launch shape.
+struct VarPlanHost;
+struct VarWorkspace {
+    void *slab = nullptr, *vslab = nullptr, *bscratch = nullptr, *plan_dev = nullptr;
+    size_t slab_bytes = 0, vslab_bytes = 0, bscratch_bytes = 0, plan_bytes = 0;
+    VarPlanHost* plan = nullptr;            // host copy of the plan resident in plan_dev
+    int64_t key_cols = -1; int key_nbi = 0, key_ntask = 0, key_P = 0;
+    int64_t allocs = 0;                     // number of (re)allocations so far (tests / gpt_reserve)
+};
+// Builds (or re-uses) the plan for M queries x `ncomp` columns and makes every buffer large enough; may synchronise
+// `s` and reallocate.  Call before launch_var with the same arguments.
+hipError_t var_prepare(VarWorkspace& ws, hipStream_t s, const KernelParams& p, int64_t M, int ncomp);
+// hdr: the model blob's header (device), hdr[16 + t] = prior variance of task t.
+void launch_var(hipStream_t s, const KernelParams& p, const VarWorkspace& ws, const void* Xs, const void* Wf,
+                const void* Xq, int64_t M, int ncomp, void* var, void* Jvar, void* dvar, const double* hdr);
+void var_release(VarWorkspace& ws);
+int var_workgroups();
+
+size_t wf_elems(int NP);          // elements of ONE task's tile set (+ prefetch overrun after the last task: wf_overrun_elems)
+size_t wf_overrun_elems();
 
 }  // namespace gpt

@@ -52,4 +52,16 @@ __device__ __forceinline__ double kernel_tab(const double h, const double lnc, c
     return (1.0 + t + t * t * (1.0 / 3.0)) * exp_tab(lnc - t, T);
 }
 
+// fp32 variant (models fitted with GPT_F32): the hardware's v_exp_f32 (2^x, ~1 ulp) — no table, no DP instructions.
+template <int KT>
+__device__ __forceinline__ float kernel_tab(const float h, const float lnc, const double* __restrict__ /*unused*/) {
+    constexpr float L2E = 1.44269504088896341f;
+    if (KT == KT_RBF) return __builtin_amdgcn_exp2f((lnc - h) * L2E);
+    const float r = __builtin_sqrtf(h + h);
+    if (KT == KT_MATERN12) return __builtin_amdgcn_exp2f((lnc - r) * L2E);
+    if (KT == KT_MATERN32) { const float t = 1.7320508075688772f * r; return (1.0f + t) * __builtin_amdgcn_exp2f((lnc - t) * L2E); }
+    const float t = 2.23606797749979f * r;
+    return (1.0f + t + t * t * (1.0f / 3.0f)) * __builtin_amdgcn_exp2f((lnc - t) * L2E);
+}
+
 }  // namespace gpt

@@ -646,11 +646,9 @@ template <bool BT, bool AT, int TS>
 static void launch_gemm_ts(hipStream_t s, const GemmArgs& g) {
     const GemmGrid q = gemm_grid(g, TS);
     constexpr size_t lds = (size_t)((AT ? 32 * (TS + 16) : TS * GA_S) + (BT ? TS * GA_S : 32 * (TS + 16))) * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce once;
+    if (once.first())
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<BT, AT, TS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
     hipLaunchKernelGGL((k_gemm<BT, AT, TS>), dim3(q.nvid), dim3(256), lds, s, g, q.TM, q.TN, q.G, q.fold_tm);
 }
 
@@ -692,11 +690,10 @@ void launch_potrf(hipStream_t s, double* K, double* W, int NP, int* info) {
     const int ob = potrf_outer_blocks();
     constexpr size_t step_lds = (size_t)(2 * NB * PS) * sizeof(double);
     constexpr size_t fin_lds = (size_t)(2 * NB * DS) * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce once;
+    if (once.first()) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_step), hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_finish), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fin_lds);
-        attr_set = true;
     }
     // Third level: panels are grouped by `grp`.  Inside a group a panel's own columns receive the group's earlier panels
     // just before its steps (a thin GEMM, K = up to (grp-1) panels); everything behind the group is updated once per
@@ -846,16 +843,19 @@ void launch_alpha(hipStream_t s, const double* W, const double* Y4, int N, int N
 // Rows/cols >= N (padding) are zeroed so padded sources never reach a variance.
 // One workgroup transposes a 64-row x 128-col sub-block through LDS (coalesced on both sides).
 // =====================================================================================
-size_t wf_doubles(int NP) {
+size_t wf_elems(int NP) {
     const size_t nb = NP / WT;
-    return nb * (nb + 1) / 2 * WT_TILE_DOUBLES + WT_STEP_DOUBLES;   // + one k4-step of prefetch overrun
+    return nb * (nb + 1) / 2 * WT_TILE_DOUBLES;
 }
+size_t wf_overrun_elems() { return WT_STEP_DOUBLES; }     // one k4-step of prefetch overrun behind the last tile set
 
 constexpr int PKR = 64;          // sub-block: one 64-row group ...
 constexpr int PKC = 128;         // ... x 128 columns (32 k4-steps); 65 KB of LDS, two workgroups per CU
 constexpr int PK_S = PKC + 1;
 
-__global__ __launch_bounds__(256) void k_pack_w(const double* __restrict__ W, int N, int NP, double* __restrict__ Wf) {
+// TO = double: [k4][g][q 0..2)[lane][p 0..2) (row tile 2q + p);  TO = float: [k4][g][lane][e 0..4) (row tile e).
+template <typename TO>
+__global__ __launch_bounds__(256) void k_pack_w(const double* __restrict__ W, int N, int NP, TO* __restrict__ Wf, double scale) {
     extern __shared__ __attribute__((aligned(16))) double tile[];   // [PKR][PK_S]
     constexpr int SUBR = WT / PKR, SUBC = WT / PKC;                  // sub-blocks per tile edge (8 x 4)
     const int ib = blockIdx.y / SUBR, g = blockIdx.y % SUBR;        // g: row group of the tile
@@ -873,34 +873,67 @@ __global__ __launch_bounds__(256) void k_pack_w(const double* __restrict__ W, in
             if (gc + 1 > gr || gc + 1 >= N) v[1] = 0.0;
             if (gc >= N) v[0] = 0.0;
         }
-        tile[r * PK_S + c] = v[0];
-        tile[r * PK_S + c + 1] = v[1];
+        tile[r * PK_S + c] = v[0] * scale;
+        tile[r * PK_S + c + 1] = v[1] * scale;
     }
     __syncthreads();
-    d2* out = reinterpret_cast<d2*>(Wf + ((size_t)ib * (ib + 1) / 2 + kb) * WT_TILE_DOUBLES);
+    TO* out = Wf + ((size_t)ib * (ib + 1) / 2 + kb) * WT_TILE_DOUBLES;
     // this sub-block covers k4 in [32 kc, 32 kc + 32) of row group g
-    for (int e = t; e < (PKC / 4) * 2 * 64; e += 256) {
-        const int lane = e & 63, q = (e >> 6) & 1, k4l = e >> 7;
-        const int lc = lane & 15, lk = lane >> 4;
-        const int col = 4 * k4l + lk;
-        const int rowb = 16 * (2 * q) + lc;
-        const double v0 = tile[rowb * PK_S + col];
-        const double v1 = tile[(rowb + 16) * PK_S + col];
-        const int k4 = (PKC / 4) * kc + k4l;
-        out[((size_t)(k4 * WT_GROUPS + g) * 2 + q) * 64 + lane] = d2{v0, v1};
+    if (std::is_same<TO, double>::value) {
+        d2* o2 = reinterpret_cast<d2*>(out);
+        for (int e = t; e < (PKC / 4) * 2 * 64; e += 256) {
+            const int lane = e & 63, q = (e >> 6) & 1, k4l = e >> 7;
+            const int lc = lane & 15, lk = lane >> 4;
+            const int col = 4 * k4l + lk;
+            const int rowb = 16 * (2 * q) + lc;
+            const double v0 = tile[rowb * PK_S + col];
+            const double v1 = tile[(rowb + 16) * PK_S + col];
+            const int k4 = (PKC / 4) * kc + k4l;
+            o2[((size_t)(k4 * WT_GROUPS + g) * 2 + q) * 64 + lane] = d2{v0, v1};
+        }
+    } else {
+        f4* o4 = reinterpret_cast<f4*>(out);
+        for (int e = t; e < (PKC / 4) * 64; e += 256) {
+            const int lane = e & 63, k4l = e >> 6;
+            const int lc = lane & 15, lk = lane >> 4;
+            const int col = 4 * k4l + lk;
+            const int k4 = (PKC / 4) * kc + k4l;
+            o4[(size_t)(k4 * WT_GROUPS + g) * 64 + lane] =
+                f4{(float)tile[lc * PK_S + col], (float)tile[(16 + lc) * PK_S + col], (float)tile[(32 + lc) * PK_S + col],
+                   (float)tile[(48 + lc) * PK_S + col]};
+        }
     }
 }
 
-void launch_pack_w(hipStream_t s, const double* W, int N, int NP, double* Wf) {
+void launch_pack_w(hipStream_t s, const double* W, int N, int NP, void* Wf, int dtype, int task, double scale) {
     const int nbt = NP / WT;
     const size_t lds = (size_t)PKR * PK_S * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_pack_w), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
+    static PerDeviceOnce once;
+    if (once.first()) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_pack_w<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_pack_w<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
-    hipLaunchKernelGGL(k_pack_w, dim3(nbt * (WT / PKC), nbt * (WT / PKR)), dim3(256), lds, s, W, N, NP, Wf);
-    hipMemsetAsync(Wf + (wf_doubles(NP) - WT_STEP_DOUBLES), 0, WT_STEP_DOUBLES * sizeof(double), s);
+    const dim3 grid(nbt * (WT / PKC), nbt * (WT / PKR));
+    const size_t off = (size_t)task * wf_elems(NP);
+    if (dtype == DT_F32) hipLaunchKernelGGL(k_pack_w<float>, grid, dim3(256), lds, s, W, N, NP, static_cast<float*>(Wf) + off, scale);
+    else hipLaunchKernelGGL(k_pack_w<double>, grid, dim3(256), lds, s, W, N, NP, static_cast<double*>(Wf) + off, scale);
+}
+
+// dst[r][dst_col0 + c] = src[r][src_col0 + c] * scale for c < ncol: moves alpha columns from the fp64 fit workspace into
+// the model blob's A4 image (element type of the model; the SVGP model puts task t's single column at column t,
+// times the task's outputscale).
+template <typename TO>
+__global__ __launch_bounds__(256) void k_store4(const double* __restrict__ src4, int rows, TO* __restrict__ dst4, int src_col0,
+                                                int dst_col0, int ncol, double scale) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    for (int c = 0; c < ncol; ++c) dst4[(size_t)r * 4 + dst_col0 + c] = (TO)(src4[(size_t)r * 4 + src_col0 + c] * scale);
+}
+
+void launch_store4(hipStream_t s, const double* src4, int rows, void* dst4, int dtype, int src_col0, int dst_col0, int ncol, double scale) {
+    const dim3 grid((rows + 255) / 256);
+    if (dtype == DT_F32) hipLaunchKernelGGL(k_store4<float>, grid, dim3(256), 0, s, src4, rows, static_cast<float*>(dst4), src_col0, dst_col0, ncol, scale);
+    else hipLaunchKernelGGL(k_store4<double>, grid, dim3(256), 0, s, src4, rows, static_cast<double*>(dst4), src_col0, dst_col0, ncol, scale);
 }
 
 // =====================================================================================

@@ -1,4 +1,5 @@
-// Prediction kernels for gfx950 (MI355X).
+// Prediction kernels for gfx950 (MI355X), templated on the element type (fp64: the exact-GP path of the reference;
+// fp32: its SVGP exact-conversion path, which the reference computes in fp32 torch).
 //
 //  k_mean_jac : posterior mean  mu[m,o] = sum_n k(x_m, X_n) alpha[n,o]   (sklearn/_gpr.py:443-444)
 //               and Jacobian    J[m,o,d] = sum_n (X[n,d]-x[m,d])/l_d^2 k(x_m,X_n) alpha[n,o]
@@ -9,59 +10,111 @@
 //  k_var      : posterior variance  c + s^2 - |W k*|^2  (sklearn/_gpr.py:454-485 does L \ k*; here
 //               W = L^-1 is explicit so the solve becomes a triangular GEMM), the Jacobian variance
 //               c/l_d^2 - |W dk_d|^2 (gaussian_process.py:95-98) and d var/dx_d = -2 (W dk_d).(W k*)
-//               (gaussian_process.py:122-125) on the fp64 matrix cores; design notes at the kernel.
+//               (gaussian_process.py:122-125) on the matrix cores; design notes at the kernel.  With ntask > 1 the
+//               A operand is the stack of the tasks' inverse factors (each pre-scaled by its outputscale) and
+//               the kernel columns are shared by all tasks: the SVGP exact-conversion model,
+//               models/torch/stocastic_variational_gaussian_process_derivatives.py:113-153.
 #include "gpt_common.h"
 #include "gpt_exp.h"
+#include "gpt_plan.h"
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 namespace gpt {
 
 // ------------------------------------------------------------------------------------------
+// Element-type traits: vector types, the MFMA, and the layout unit of the A stream Wf.
+//   fp64: per (k4-step, row group) two d2 per lane (row tiles 0,1 | 2,3): [q 0..2)[lane 0..64)[p 0..2)
+//   fp32: per (k4-step, row group) one f4 per lane (row tiles 0..3):       [lane 0..64)[e 0..4)
+// 16 B per lane and load either way; the v_mfma_*_16x16x4 A/B lane maps are the same for both types.
+// ------------------------------------------------------------------------------------------
+template <typename T> struct El;
+template <> struct El<double> {
+    typedef d4 v4;
+    typedef d2 avec;
+    static constexpr int A_STEP = 1024, A_GROUP = 128;     // avec per k4-step of a tile / per row group inside it
+    struct AF { d2 lo, hi; };
+    static __device__ __forceinline__ void lda(AF& a, const avec* __restrict__ p, const int lane) { a.lo = p[lane]; a.hi = p[lane + 64]; }
+    static __device__ __forceinline__ void keep(const AF& a, const v4& b) { asm volatile("" :: "v"(a.lo), "v"(a.hi), "v"(b)); }
+    static __device__ __forceinline__ v4 mfma(const double a, const double b, const v4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ void mfma16(v4 (&acc)[4][4], const AF& a, const v4& b) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            acc[0][t] = mfma(a.lo[0], b[t], acc[0][t]);
+            acc[1][t] = mfma(a.lo[1], b[t], acc[1][t]);
+            acc[2][t] = mfma(a.hi[0], b[t], acc[2][t]);
+            acc[3][t] = mfma(a.hi[1], b[t], acc[3][t]);
+        }
+    }
+};
+template <> struct El<float> {
+    typedef f4 v4;
+    typedef f4 avec;
+    static constexpr int A_STEP = 512, A_GROUP = 64;
+    struct AF { f4 v; };
+    static __device__ __forceinline__ void lda(AF& a, const avec* __restrict__ p, const int lane) { a.v = p[lane]; }
+    static __device__ __forceinline__ void keep(const AF& a, const v4& b) { asm volatile("" :: "v"(a.v), "v"(b)); }
+    static __device__ __forceinline__ v4 mfma(const float a, const float b, const v4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ void mfma16(v4 (&acc)[4][4], const AF& a, const v4& b) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            acc[0][t] = mfma(a.v[0], b[t], acc[0][t]);
+            acc[1][t] = mfma(a.v[1], b[t], acc[1][t]);
+            acc[2][t] = mfma(a.v[2], b[t], acc[2][t]);
+            acc[3][t] = mfma(a.v[3], b[t], acc[3][t]);
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------
 // OC = outputs handled by this pass (1..4): only their partial sums are accumulated.
-template <int QPW, int OC, int KT>
-__global__ __launch_bounds__(256) void k_mean_jac(KernelParams p, const double* __restrict__ Xs,
-                                                  const double* __restrict__ A4, const double* __restrict__ Xq,
-                                                  int64_t M, int o_base, double* __restrict__ mean,
-                                                  double* __restrict__ J) {
+template <typename T, int QPW, int OC, int KT>
+__global__ __launch_bounds__(256) void k_mean_jac(KernelParams p, const T* __restrict__ Xs,
+                                                  const T* __restrict__ A4, const T* __restrict__ Xq,
+                                                  int64_t M, int o_base, T* __restrict__ mean,
+                                                  T* __restrict__ J) {
+    typedef typename El<T>::v4 v4;
     __shared__ double Tt[256];
-    Tt[threadIdx.x] = g_exp2_table[threadIdx.x];
-    __syncthreads();
+    if (std::is_same<T, double>::value) {
+        Tt[threadIdx.x] = g_exp2_table[threadIdx.x];
+        __syncthreads();
+    }
     const int lane = threadIdx.x & 63;
     const int64_t m0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * QPW;
     if (m0 >= M) return;
     const int D = p.D;
-    constexpr double RS2 = 0.70710678118654752440;    // coordinates scaled by 1/sqrt(2): k = exp(ln c - |d'|^2)
-    double q[QPW][3];
+    constexpr T RS2 = (T)0.70710678118654752440;    // coordinates scaled by 1/sqrt(2): k = exp(ln c - |d'|^2)
+    T q[QPW][3];
 #pragma unroll
     for (int i = 0; i < QPW; ++i) {
         const int64_t m = (m0 + i < M) ? (m0 + i) : (M - 1);
 #pragma unroll
-        for (int d = 0; d < 3; ++d) q[i][d] = (d < D) ? Xq[m * D + d] * (p.inv_ls[d] * RS2) : 0.0;
+        for (int d = 0; d < 3; ++d) q[i][d] = (d < D) ? Xq[m * D + d] * (T)(p.inv_ls[d] * 0.70710678118654752440) : (T)0;
     }
-    double acc[QPW][OC][4];
+    T acc[QPW][OC][4];
 #pragma unroll
     for (int i = 0; i < QPW; ++i)
 #pragma unroll
         for (int o = 0; o < OC; ++o)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[i][o][e] = 0.0;
+            for (int e = 0; e < 4; ++e) acc[i][o][e] = (T)0;
 
-    const double lnc = p.lnc;
+    const T lnc = (T)p.lnc;
     for (int n = lane; n < p.N; n += 64) {
-        const d4 xs = *reinterpret_cast<const d4*>(Xs + (size_t)n * 4);
-        const d4 al = *reinterpret_cast<const d4*>(A4 + (size_t)n * 4);
-        const double x0 = xs[0] * RS2, x1 = xs[1] * RS2, x2 = xs[2] * RS2;
+        const v4 xs = *reinterpret_cast<const v4*>(Xs + (size_t)n * 4);
+        const v4 al = *reinterpret_cast<const v4*>(A4 + (size_t)n * 4);
+        const T x0 = xs[0] * RS2, x1 = xs[1] * RS2, x2 = xs[2] * RS2;
 #pragma unroll
         for (int i = 0; i < QPW; ++i) {
-            const double d0 = x0 - q[i][0], d1 = x1 - q[i][1], d2 = x2 - q[i][2];
-            double hh = d0 * d0;
+            const T d0 = x0 - q[i][0], d1 = x1 - q[i][1], d2 = x2 - q[i][2];
+            T hh = d0 * d0;
             hh = fma(d1, d1, hh);
             hh = fma(d2, d2, hh);
-            const double kv = kernel_tab<KT>(hh, lnc, Tt);
+            const T kv = kernel_tab<KT>(hh, lnc, Tt);
 #pragma unroll
             for (int o = 0; o < OC; ++o) {
-                const double t = kv * al[o];
+                const T t = kv * al[o];
                 acc[i][o][0] += t;
                 acc[i][o][1] += t * d0;
                 acc[i][o][2] += t * d1;
@@ -75,7 +128,7 @@ __global__ __launch_bounds__(256) void k_mean_jac(KernelParams p, const double* 
         for (int o = 0; o < OC; ++o)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                double v = acc[i][o][e];
+                T v = acc[i][o][e];
 #pragma unroll
                 for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s);
                 acc[i][o][e] = v;
@@ -94,24 +147,24 @@ __global__ __launch_bounds__(256) void k_mean_jac(KernelParams p, const double* 
                 if (J) {
 #pragma unroll
                     for (int d = 0; d < 3; ++d)
-                        if (d < D) J[(m * O + oo) * D + d] = acc[i][o][1 + d] * (p.inv_ls[d] * S2);
+                        if (d < D) J[(m * O + oo) * D + d] = acc[i][o][1 + d] * (T)(p.inv_ls[d] * S2);
                 }
             }
         }
     }
 }
 
-void launch_mean_jac(hipStream_t s, const KernelParams& p, const double* Xs, const double* A4,
-                     const double* Xq, int64_t M, double* mean, double* J) {
-    if (M <= 0 || (!mean && !J)) return;
+template <typename T>
+static void launch_mean_jac_t(hipStream_t s, const KernelParams& p, const T* Xs, const T* A4,
+                              const T* Xq, int64_t M, T* mean, T* J) {
     constexpr int QPW = 2;
     const int64_t waves = (M + QPW - 1) / QPW;
     const int64_t blocks = (waves + 3) / 4;
     for (int ob = 0; ob < p.O; ob += 4) {
         const int cnt = (p.O - ob) < 4 ? (p.O - ob) : 4;
-        const double* a4 = A4 + (size_t)(ob / 4) * p.NP * 4;
+        const T* a4 = A4 + (size_t)(ob / 4) * p.NP * 4;
         const dim3 grid((unsigned)blocks);
-#define GPT_MJ(OC_, KT_) hipLaunchKernelGGL((k_mean_jac<QPW, OC_, KT_>), grid, dim3(256), 0, s, p, Xs, a4, Xq, M, ob, mean, J)
+#define GPT_MJ(OC_, KT_) hipLaunchKernelGGL((k_mean_jac<T, QPW, OC_, KT_>), grid, dim3(256), 0, s, p, Xs, a4, Xq, M, ob, mean, J)
 #define GPT_MJ_K(OC_)                                     \
         switch (p.ktype) {                                 \
             case KT_MATERN12: GPT_MJ(OC_, KT_MATERN12); break; \
@@ -130,11 +183,21 @@ void launch_mean_jac(hipStream_t s, const KernelParams& p, const double* Xs, con
     }
 }
 
+void launch_mean_jac(hipStream_t s, const KernelParams& p, const void* Xs, const void* A4,
+                     const void* Xq, int64_t M, void* mean, void* J) {
+    if (M <= 0 || (!mean && !J)) return;
+    if (p.dtype == DT_F32)
+        launch_mean_jac_t<float>(s, p, (const float*)Xs, (const float*)A4, (const float*)Xq, M, (float*)mean, (float*)J);
+    else
+        launch_mean_jac_t<double>(s, p, (const double*)Xs, (const double*)A4, (const double*)Xq, M, (double*)mean, (double*)J);
+}
+
 // ------------------------------------------------------------------------------------------
 // Variance kernel.
 //
 // What the hardware does (measured on MI355X, profiles/r01_*):
-//   * v_mfma_f64_16x16x4_f64 issues every 64 cycles per SIMD: 77.7 TFLOP/s with 2 waves/SIMD at 2.4 GHz;
+//   * v_mfma_f64_16x16x4_f64 issues every 64 cycles per SIMD: 77.7 TFLOP/s with 2 waves/SIMD at 2.4 GHz
+//     (v_mfma_f32_16x16x4_f32 every 32: 155 TFLOP/s);
 //   * every fp64 VALU instruction of a SIMD takes ~4.5 cycles away from its fp64 MFMA stream (the fp64
 //     matrix and vector paths share the DP units), so B values must be generated once, not per wave;
 //   * a workgroup barrier every 8 k-steps costs ~4 %; once the matrix pipe is >90 % busy the chip lowers
@@ -142,25 +205,23 @@ void launch_mean_jac(hipStream_t s, const KernelParams& p, const double* Xs, con
 //     (A from L2 with all workgroups walking W in step, B from LDS), not from HBM.
 // Design:
 //   * a workgroup (512 threads = 8 waves, 2 per SIMD) owns a 64-column block and sweeps the 512-row
-//     i-blocks, longest sweep first; wave w accumulates the 64x64 product of its 64-row group (16 MFMA
-//     tiles, 128 VGPRs) and folds it into per-column sums when the sweep ends, so V = W K*^T never
-//     touches memory;
+//     i-blocks of every task, longest sweep first; wave w accumulates the 64x64 product of its 64-row group (16 MFMA
+//     tiles) and folds it into per-column sums when the sweep ends, so V = W K*^T never touches memory
+//     (a sweep that the work split cut along k stores its partial product instead: gpt_plan.h);
 //   * the B operand of a sweep reaches the waves through a double-buffered LDS image in MFMA lane order,
-//     2 x 32 k-steps x 2 KiB = 128 KiB, one barrier per 32 k-steps.  Wave w fills k-steps w, w+8, w+16,
+//     2 x 32 k-steps, one barrier per 32 k-steps.  Wave w fills k-steps w, w+8, w+16,
 //     w+24 of the next chunk from the middle of its own MFMA run (the two waves of a SIMD staggered).
-//     In the FIRST sweep of a block the fragments are generated (k* / dk_d columns, one table-driven fp64
-//     exp each, gpt_exp.h) and a copy goes to this workgroup's scratch image in HBM/L2 ([k-step][lane][4],
-//     4 MB at N=8192); the other sweeps reload them from there (2 KiB per k-step per workgroup) — so a
+//     In a GENERATING sweep the fragments are computed (k* / dk_d columns, one exp each: table-driven in fp64,
+//     gpt_exp.h, v_exp_f32 in fp32) and a copy goes to this workgroup's scratch image in HBM/L2
+//     ([k-step][lane][4]); the other sweeps of the block reload them from there — so a
 //     block pays N exps per column, not N*(N/512+1)/2;
-//   * the A operand streams from the fragment-ordered image Wf with two 16-byte loads per lane and
-//     k-step, two steps ahead; in the diagonal tile a wave skips the k-steps where its row group is
+//   * the A operand streams from the fragment-ordered image Wf with 16-byte loads per lane,
+//     two k-steps ahead; in the diagonal tile a wave skips the k-steps where its row group is
 //     entirely above the diagonal (wave g has 16 (g + 1) of 128), row groups paired (0,7)(1,6)(2,5)(3,4) on
 //     the SIMDs.  In the reload sweeps the diagonal tile runs OUTSIDE the lock-step LDS pipeline (every wave
 //     on its own, B straight from the scratch image), so the pairing balances it: 0.56 of a full tile
 //     instead of 0.75 (+2.7 %);
-//   * work split: rounds of whole blocks (all workgroups in step => W tiles are shared through L2), then
-//     a stream-K split of the leftover blocks; partial column sums go to unique slab slots and
-//     k_var_finalize adds them in fixed order (deterministic, no atomics).
+//   * work split: gpt_plan.h (rounds of whole blocks, then an explicit item list cut at tile granularity).
 // Alternatives measured and dropped (profiles/r01_kvar_variant_ab.txt): per-wave B generation (v1, 53 TF),
 // 8-step chunks (-3.7 %), barrier-free sweeps with every wave reading B from the scratch image (-3 %: L2
 // hit rate 97 % -> 56 %, 3.4 TB/s from beyond L2, clock 2.18 GHz), deeper A prefetch (0 %).
@@ -173,124 +234,96 @@ void launch_mean_jac(hipStream_t s, const KernelParams& p, const double* Xs, con
 #ifndef GPT_ABL
 #define GPT_ABL 0
 #endif
-constexpr int VAR_COLS = 64;        // columns per column block
 constexpr int VAR_SUB = 8;          // k4-steps per sub-chunk (= waves per workgroup: wave w fills step w of each)
 constexpr int VAR_SUBS = 4;         // sub-chunks per LDS chunk
 constexpr int VAR_CH = VAR_SUB * VAR_SUBS;   // k4-steps per LDS chunk, one barrier each (32)
-constexpr size_t VAR_LDS_BYTES = (size_t)2 * VAR_CH * 64 * 4 * sizeof(double);   // 128 KiB
-constexpr int VAR_DIAG_COST = 72;   // k4-steps a diagonal tile costs a SIMD: waves g and 7-g, 16 (g+1) + 16 (8-g) of 2 x 128, halved
-constexpr int VAR_SLOT = 2 * VAR_COLS;   // doubles per slab slot: ssq[64], crs[64]
+template <typename T> constexpr size_t var_lds_bytes() { return (size_t)2 * VAR_CH * 64 * 4 * sizeof(T); }   // 128 KiB fp64 / 64 KiB fp32
 
-// Work split.  Rounds 0..R-1: workgroup p takes the whole column block r*P + p — all workgroups then walk
-// the same W tiles at the same time, which is what keeps the W stream in L2 (each XCD's 32 workgroups
-// share one copy).  The ncb - R*P blocks left over ("tail") are laid end to end, costed per i-block, and
-// cut into P equal ranges (stream-K) so that every CU finishes together.
-struct VarPlan {
-    int64_t ncb;     // column blocks
-    int64_t nfull;   // R * P blocks handled whole, round-robin
-    int64_t ncb_t;   // tail blocks = ncb - nfull
-    int64_t T;       // cost of one column block (all i-blocks)
-    int64_t U;       // tail cost = ncb_t * T
-    int P;           // workgroups
-    int nbi;         // i-blocks
-};
-
-__host__ __device__ inline int64_t var_cost_prefix(int ib) {          // sum_{i<ib} (128 i + VAR_DIAG_COST)
-    return (int64_t)64 * ib * (ib - 1) + (int64_t)VAR_DIAG_COST * ib;
-}
-
-// first work unit (tail column block, i-block) of tail range p; p = P gives the end of the tail
-__host__ __device__ inline void var_boundary(const VarPlan& pl, int p, int64_t& cb, int& ib) {
-    if (p >= pl.P) { cb = pl.ncb_t; ib = 0; return; }
-    const int64_t B = pl.U / pl.P * p + (pl.U % pl.P) * p / pl.P;
-    cb = B / pl.T;
-    const int64_t off = B % pl.T;
-    int lo = 0, hi = pl.nbi;                                            // smallest ib with prefix(ib) >= off
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (var_cost_prefix(mid) >= off) hi = mid; else lo = mid + 1;
-    }
-    ib = lo;
-    if (ib >= pl.nbi) { cb += 1; ib = 0; }
-}
-
-#define GPT_MFMA16(acc, a01, a23, b)                                                              \
-    _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) {                                            \
-        acc[0][t_] = __builtin_amdgcn_mfma_f64_16x16x4f64((a01)[0], (b)[t_], acc[0][t_], 0, 0, 0); \
-        acc[1][t_] = __builtin_amdgcn_mfma_f64_16x16x4f64((a01)[1], (b)[t_], acc[1][t_], 0, 0, 0); \
-        acc[2][t_] = __builtin_amdgcn_mfma_f64_16x16x4f64((a23)[0], (b)[t_], acc[2][t_], 0, 0, 0); \
-        acc[3][t_] = __builtin_amdgcn_mfma_f64_16x16x4f64((a23)[1], (b)[t_], acc[3][t_], 0, 0, 0); \
-    }
-
-template <int NCOMP, bool CROSS, int KT>
-__global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlan pl, const double* __restrict__ Xs,
-                                                const double* __restrict__ Wf, const double* __restrict__ Xq,
-                                                int64_t M, double* __restrict__ slab, double* __restrict__ bscratch) {
-    extern __shared__ __attribute__((aligned(16))) double Bs_dyn[];       // [buffer][k4-step][lane][column tile]
-    __shared__ double red[2][8][VAR_COLS];
+template <typename T, int NCOMP, bool CROSS, int KT>
+__global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, const T* __restrict__ Xs,
+                                                const T* __restrict__ Wf, const T* __restrict__ Xq,
+                                                int64_t M, T* __restrict__ slab, T* __restrict__ vslab, T* __restrict__ bscratch) {
+    typedef typename El<T>::v4 v4;
+    typedef typename El<T>::avec avec;
+    typedef typename El<T>::AF AF;
+    constexpr size_t A_STEP = El<T>::A_STEP;
+    extern __shared__ __attribute__((aligned(16))) unsigned char Bs_raw[];       // [buffer][k4-step][lane][column tile]
+    T* const Bs_dyn = reinterpret_cast<T*>(Bs_raw);
+    __shared__ T red[2][8][VAR_COLS];
     __shared__ double Tt[256];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lc = lane & 15, lk = lane >> 4;
     const int g = (w < 4) ? w : (11 - w);     // row group of this wave: 0,1,2,3,7,6,5,4
     const int D = p.D;
-    auto Bs = [&](const int buf, const int step) -> double* { return Bs_dyn + ((size_t)(buf * VAR_CH + step) * 64 + lane) * 4; };
-    if (threadIdx.x < 256) Tt[threadIdx.x] = g_exp2_table[threadIdx.x];
+    auto Bs = [&](const int buf, const int step) -> T* { return Bs_dyn + ((size_t)(buf * VAR_CH + step) * 64 + lane) * 4; };
+    if (std::is_same<T, double>::value && threadIdx.x < 256) Tt[threadIdx.x] = g_exp2_table[threadIdx.x];
 
-    int64_t cb0, cb1; int ib0, ib1;            // this workgroup's range of the tail
-    var_boundary(pl, blockIdx.x, cb0, ib0);
-    var_boundary(pl, blockIdx.x + 1, cb1, ib1);
-    const int64_t rounds = pl.nfull / pl.P;
-
-    constexpr double RS2 = 0.70710678118654752440;    // coordinates are pre-scaled by 1/sqrt(2): t = ln c - |d'|^2
+    constexpr T RS2 = (T)0.70710678118654752440;    // coordinates are pre-scaled by 1/sqrt(2): t = ln c - |d'|^2
     // NCOMP=4: column = 4 query + comp, comp = lc & 3 in every tile: b = kv * (cbv + sum_d cd[d] * d'_d).
     // NCOMP=3 (Jacobian variance alone, no k* column): column = D query + d, D columns per query; for D = 3 the d of a
     // lane's column changes from tile to tile and from block to block (16 = 64 = 1 mod 3), selected in `produce`.
     const int comp = (NCOMP == 4) ? (lc & 3) : 0;
-    const double cbv = (comp == 0) ? 1.0 : 0.0;
-    double cd[3];
+    const T cbv = (comp == 0) ? (T)1 : (T)0;
+    T cd[3];
 #pragma unroll
-    for (int d = 0; d < 3; ++d) cd[d] = (comp == d + 1 && d < D) ? p.inv_ls[d] * 1.41421356237309504880 : 0.0;
-    const double lnc = p.lnc;
+    for (int d = 0; d < 3; ++d) cd[d] = (comp == d + 1 && d < D) ? (T)(p.inv_ls[d] * 1.41421356237309504880) : (T)0;
+    const T lnc = (T)p.lnc;
     const int nbi = pl.nbi;
-    // A stream in d2 units: element (step S, group g, q, lane) at ((S*8 + g)*2 + q)*64 + lane
-    // uniform base + per-lane 32-bit offset (scalar-base addressing: no 64-bit VALU address arithmetic, and no VALU
-    // writes into registers that loads are still in flight to)
-    const d2* const wuni = reinterpret_cast<const d2*>(Wf) + (size_t)g * 128;
-    const int wlane = lane;
-    constexpr size_t STEP_D2 = WT_STEP_DOUBLES / 2;   // 1024
-    // this workgroup's B image in d2 units: k-step s, lane l at (s*64 + l)*2 (+1)
-    d2* const buni = reinterpret_cast<d2*>(bscratch) + (size_t)blockIdx.x * ((size_t)p.NP * 32);
-    const int blane = lane * 2;
+    // A stream: element (step S, group g, ...) — uniform base + per-lane 32-bit offset (scalar-base addressing: no
+    // 64-bit VALU address arithmetic, and no VALU writes into registers that loads are still in flight to)
+    const avec* const wuni = reinterpret_cast<const avec*>(Wf) + (size_t)g * El<T>::A_GROUP;
+    // this workgroup's B image: k-step s, lane l at s*64 + l (v4 units)
+    v4* const buni = reinterpret_cast<v4*>(bscratch) + (size_t)blockIdx.x * ((size_t)p.NP * 16);
 
-    for (int64_t piece = 0;; ++piece) {
-        int64_t cb, slot; int lo, hi;
-        if (piece < rounds) {                          // whole block, in step with every other workgroup
-            cb = piece * pl.P + blockIdx.x; slot = cb; lo = 0; hi = nbi;
-        } else {                                       // this workgroup's share of the tail
-            const int64_t cbt = cb0 + (piece - rounds);
-            if (cbt > cb1 || cbt >= pl.ncb_t) break;
-            lo = (cbt == cb0) ? ib0 : 0;
-            hi = (cbt == cb1) ? ib1 : nbi;
-            if (lo >= hi) continue;
-            cb = pl.nfull + cbt; slot = pl.nfull + blockIdx.x + cbt;
+    const int64_t rounds = pl.nfull / pl.P;
+    const int per_block = pl.ntask * nbi;                       // sweeps of a whole block
+    const int64_t n_implicit = rounds * per_block;
+    const int it_begin = pl.item_begin[blockIdx.x], it_end = pl.item_begin[blockIdx.x + 1];
+
+    T ssq[4] = {0, 0, 0, 0}, crs[4] = {0, 0, 0, 0};
+    for (int64_t it = 0;; ++it) {
+        // ---- next item: derived (rounds of whole blocks, in step with every other workgroup) or listed (tail)
+        int64_t cb; int task, ib, k_lo, k_hi, flags, slot, vslot;
+        if (it < n_implicit) {
+            const int64_t rnd = it / per_block;
+            const int r = (int)(it - rnd * per_block);
+            task = r / nbi;
+            ib = nbi - 1 - (r - task * nbi);
+            cb = rnd * pl.P + blockIdx.x;
+            k_lo = 0; k_hi = ib + 1;
+            flags = (r == 0 ? (VI_FIRST | VI_GEN) : 0) | (ib == nbi - 1 ? VI_ZERO : 0);
+            slot = (ib == 0) ? (int)(cb * pl.ntask + task) : -1;
+            vslot = -1;
+        } else {
+            const int64_t idx = it_begin + (it - n_implicit);
+            if (idx >= it_end) break;
+            const VarItem item = pl.items[idx];
+            cb = item.cb; task = item.task; ib = item.ib; k_lo = item.k_lo; k_hi = item.k_hi;
+            flags = item.flags; slot = item.slot; vslot = item.vslot;
         }
-        __syncthreads();                               // LDS (Bs, red, Tt) free / ready
-        // the scratch image is about to be rewritten: drop the L1 lines of it this CU may still hold
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-
-        double ssq[4] = {0.0, 0.0, 0.0, 0.0}, crs[4] = {0.0, 0.0, 0.0, 0.0};
+        if (flags & VI_FIRST) {
+            __syncthreads();                               // LDS (Bs, red, Tt) free / ready
+            // the scratch image is about to be rewritten: drop the L1 lines of it this CU may still hold
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        } else if (flags & VI_GEN) {
+            __syncthreads();                               // nobody may still be reading the part of the image rewritten now
+        }
+        if (flags & VI_ZERO) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { ssq[t] = (T)0; crs[t] = (T)0; }
+        }
         const int base3 = (NCOMP == 3) ? (int)((cb * VAR_COLS + lc) % D) : 0;
-        const double sc3[3] = {p.inv_ls[0] * 1.41421356237309504880, p.inv_ls[1] * 1.41421356237309504880,
-                               p.inv_ls[2] * 1.41421356237309504880};
+        const T sc3[3] = {(T)(p.inv_ls[0] * 1.41421356237309504880), (T)(p.inv_ls[1] * 1.41421356237309504880),
+                          (T)(p.inv_ls[2] * 1.41421356237309504880)};
 
-        // One sweep of i-block ib.  GEN = true (first sweep of the block): B fragments are generated and a copy
-        // is kept in the scratch image; GEN = false: they are reloaded from it.  Two instantiations, so that the
-        // query coordinates and exp temporaries of the generating sweep do not occupy registers in the others.
-        auto sweep = [&](auto gen_tag, const int ib) {
+        // One sweep.  GEN = true: B fragments are generated and a copy is kept in the scratch image; GEN = false: they
+        // are reloaded from it.  Two instantiations, so that the query coordinates and exp temporaries of the generating
+        // sweep do not occupy registers in the others.
+        auto sweep = [&](auto gen_tag) {
             constexpr bool GEN = decltype(gen_tag)::value;
             // this lane's four columns (one per MFMA column tile): scaled query coordinates
-            double q[4][3];
+            T q[4][3];
             if (GEN) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
@@ -298,87 +331,84 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlan pl, cons
                     const int64_t m = (NCOMP == 1) ? col : ((NCOMP == 4) ? (col >> 2) : (col / D));
                     const int64_t mm = (m < M) ? m : (M - 1);
 #pragma unroll
-                    for (int d = 0; d < 3; ++d) q[t][d] = (d < D) ? Xq[mm * D + d] * (p.inv_ls[d] * RS2) : 0.0;
+                    for (int d = 0; d < 3; ++d) q[t][d] = (d < D) ? Xq[mm * D + d] * (T)(p.inv_ls[d] * 0.70710678118654752440) : (T)0;
                 }
             }
-            double gx[3];                                  // coordinates of the source this wave generates next
-            d2 bl[2];                                      // or the fragments it reloads next
+            T gx[3];                                       // coordinates of the source this wave generates next
+            v4 bl;                                         // or the fragments it reloads next
             auto fetch = [&](const int k4) {
                 if (GEN) {
-                    const double* xp = Xs + (size_t)(k4 * 4 + lk) * 4;
+                    const T* xp = Xs + (size_t)(k4 * 4 + lk) * 4;
                     gx[0] = xp[0]; gx[1] = xp[1]; gx[2] = xp[2];
                 } else {
-                    const d2* src = buni + (size_t)k4 * 128;
-                    bl[0] = src[blane]; bl[1] = src[blane + 1];
+                    bl = (buni + (size_t)k4 * 64)[lane];
                 }
             };
             auto produce = [&](const int buf, const int k4) {   // B fragments of k-step k4 -> LDS (+ scratch)
-                double* dstl = Bs(buf, k4 % VAR_CH);
+                T* dstl = Bs(buf, k4 % VAR_CH);
                 if (GEN) {
-                    const double x0 = gx[0] * RS2, x1 = gx[1] * RS2, x2 = gx[2] * RS2;
-                    d4 b;
+                    const T x0 = gx[0] * RS2, x1 = gx[1] * RS2, x2 = gx[2] * RS2;
+                    v4 b;
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        const double d0 = x0 - q[t][0], d1 = x1 - q[t][1], d2_ = x2 - q[t][2];
-                        double hh = d0 * d0;
+                        const T d0 = x0 - q[t][0], d1 = x1 - q[t][1], d2_ = x2 - q[t][2];
+                        T hh = d0 * d0;
                         hh = fma(d1, d1, hh);
                         hh = fma(d2_, d2_, hh);
-                        const double kv = kernel_tab<KT>(hh, lnc, Tt);
+                        const T kv = kernel_tab<KT>(hh, lnc, Tt);
                         if (NCOMP == 3) {
                             int dsel = base3 + ((D == 3) ? t : 0);            // (64 cb + 16 t + lc) mod D, base3 = (64 cb + lc) mod D
                             dsel = (dsel >= D) ? dsel - D : dsel;
-                            const double e = (dsel == 0) ? d0 * sc3[0] : ((dsel == 1) ? d1 * sc3[1] : d2_ * sc3[2]);
+                            const T e = (dsel == 0) ? d0 * sc3[0] : ((dsel == 1) ? d1 * sc3[1] : d2_ * sc3[2]);
                             b[t] = kv * e;
                         } else {
                             b[t] = (NCOMP == 1) ? kv : kv * (cbv + cd[0] * d0 + cd[1] * d1 + cd[2] * d2_);
                         }
                     }
-                    *reinterpret_cast<d4*>(dstl) = b;
-                    d2* dst = buni + (size_t)k4 * 128 + blane;
-                    dst[0] = d2{b[0], b[1]};
-                    dst[1] = d2{b[2], b[3]};
+                    *reinterpret_cast<v4*>(dstl) = b;
+                    (buni + (size_t)k4 * 64)[lane] = b;
                 } else {
-                    *reinterpret_cast<d2*>(dstl) = bl[0];
-                    *reinterpret_cast<d2*>(dstl + 2) = bl[1];
+                    *reinterpret_cast<v4*>(dstl) = bl;
                 }
             };
 
-            const size_t S_ib = (size_t)64 * ib * (ib + 1);   // stream index of the first k4-step of this sweep
-            if (GEN || ib > 0) {
+            const size_t S_ib = (size_t)task * pl.tiles_per_task * WT_K4 + (size_t)64 * ib * (ib + 1);   // stream index of k4-step 0 of this i-block
+            const bool has_diag = (k_hi == ib + 1);
+            const int K0 = k_lo * WT_K4;                                       // first k4-step of this item
+            // Reload sweeps take the diagonal tile (where wave g only has 16 (g + 1) steps of work) OUT of the lock-step
+            // LDS pipeline: see below.  A generating sweep keeps it in (its fragments are not in the scratch image yet).
+            const int lock_end = ((GEN || !has_diag) ? k_hi : ib) * WT_K4;
+            const int ch0 = K0 / VAR_CH, ch1 = lock_end / VAR_CH;              // lock-step chunks [ch0, ch1)
+            if (ch1 > ch0) {
 #pragma unroll
-                for (int j = 0; j < VAR_SUBS; ++j) {          // chunk 0: wave w fills steps w, w+8, w+16, w+24
-                    fetch(j * VAR_SUB + w);
-                    produce(0, j * VAR_SUB + w);
+                for (int j = 0; j < VAR_SUBS; ++j) {          // first chunk: wave w fills steps w, w+8, w+16, w+24
+                    fetch(K0 + j * VAR_SUB + w);
+                    produce(ch0 & 1, K0 + j * VAR_SUB + w);
                 }
             }
-            d2 a_nxt[2], a_nx2[2];                         // A fragments of the next step and of the one after it
-            a_nxt[0] = (wuni + S_ib * STEP_D2)[wlane]; a_nxt[1] = (wuni + S_ib * STEP_D2)[wlane + 64];   // step 0 is active for every group
-            a_nx2[0] = (wuni + (S_ib + 1) * STEP_D2)[wlane]; a_nx2[1] = (wuni + (S_ib + 1) * STEP_D2)[wlane + 64];   // and so is step 1
+            AF a_nxt, a_nx2;                               // A fragments of the next step and of the one after it
+            El<T>::lda(a_nxt, wuni + (S_ib + K0) * A_STEP, lane);        // the first two steps of an item are active for every group
+            El<T>::lda(a_nx2, wuni + (S_ib + K0 + 1) * A_STEP, lane);
             __syncthreads();
-            d4 acc[4][4];
+            v4 acc[4][4];
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc[r][t] = d4{0, 0, 0, 0};
-            const int nk4 = (ib + 1) * WT_K4;
-            const int my_limit = ib * WT_K4 + 16 * (g + 1);     // first k4-step of the sweep with nothing left for this group
-            // Reload sweeps take the diagonal tile (last 128 k-steps, where wave g only has 16 (g + 1) steps of work)
-            // OUT of the lock-step LDS pipeline: see below.  The generating sweep keeps it in (its fragments are
-            // not in the scratch image yet).
-            const int nchunks = (GEN ? nk4 : ib * WT_K4) / VAR_CH;
-            // Sources of the fills inside the loop, as loop-carried per-lane pointers (k-step VAR_CH + w first, then
+                for (int t = 0; t < 4; ++t) acc[r][t] = v4{0, 0, 0, 0};
+            const int my_limit = ib * WT_K4 + 16 * (g + 1);     // first k4-step of the i-block with nothing left for this group
+            // Sources of the fills inside the loop, as loop-carried per-lane pointers (k-step K0 + VAR_CH + w first, then
             // VAR_SUB further each time): an address recomputed from the k-step lands in whatever registers are free —
             // the previous fill's destination registers — and that write-after-load made hipcc drain vmcnt to 0 (and with
             // it the A fragments in flight) at the top of every sub-chunk.
-            const d2* bsrc = buni + (size_t)(VAR_CH + w) * 128 + blane;
-            const double* xsrc = Xs + (size_t)((VAR_CH + w) * 4 + lk) * 4;
+            const v4* bsrc = buni + (size_t)(K0 + VAR_CH + w) * 64 + lane;
+            const T* xsrc = Xs + (size_t)((K0 + VAR_CH + w) * 4 + lk) * 4;
             auto fetch_next = [&]() {
                 if (GEN) {
                     gx[0] = xsrc[0]; gx[1] = xsrc[1]; gx[2] = xsrc[2];
                     xsrc += VAR_SUB * 16;
                 } else {
-                    bl[0] = bsrc[0]; bl[1] = bsrc[1];
-                    bsrc += VAR_SUB * 128;
+                    bl = bsrc[0];
+                    bsrc += VAR_SUB * 64;
                 }
             };
             // the chunk body exists twice — with and without the fill of the following chunk — so that "is there a next
@@ -386,7 +416,7 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlan pl, cons
             auto chunk = [&](auto more_tag, const int ch) {
                 constexpr bool more = decltype(more_tag)::value;
                 const int cur = ch & 1;
-                d4 b_nxt = *reinterpret_cast<const d4*>(Bs(cur, 0));    // B fragments are read one k-step ahead
+                v4 b_nxt = *reinterpret_cast<const v4*>(Bs(cur, 0));    // B fragments are read one k-step ahead
                 for (int sub = 0; sub < VAR_SUBS; ++sub) {
                     const int k0 = ch * VAR_CH + sub * VAR_SUB;                 // first k-step of this sub-chunk
                     const int kn = (ch + 1) * VAR_CH + sub * VAR_SUB + w;       // the k-step this wave fills meanwhile
@@ -394,21 +424,21 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlan pl, cons
                     const bool active = (k0 < my_limit) && !(GPT_ABL == 3 && k0 >= ib * WT_K4);   // my_limit is a multiple of 16: all or nothing
                     auto step = [&](const int s) {
                         const int k4 = k0 + s;
-                        const d2 a01 = a_nxt[0], a23 = a_nxt[1];
-                        const d4 b = b_nxt;
+                        const AF a = a_nxt;
+                        const v4 b = b_nxt;
                         const int kl = my_limit - 1;
                         const size_t Sn = S_ib + ((k4 + 2 < my_limit) ? (k4 + 2) : kl);
-                        a_nxt[0] = a_nx2[0]; a_nxt[1] = a_nx2[1];
-                        if (GPT_ABL != 2) { a_nx2[0] = (wuni + Sn * STEP_D2)[wlane]; a_nx2[1] = (wuni + Sn * STEP_D2)[wlane + 64]; }
+                        a_nxt = a_nx2;
+                        if (GPT_ABL != 2) El<T>::lda(a_nx2, wuni + Sn * A_STEP, lane);
                         const int sn = sub * VAR_SUB + s + 1;
-                        if (sn < VAR_CH) b_nxt = *reinterpret_cast<const d4*>(Bs(cur, sn));
-                        if (GPT_ABL == 5) { asm volatile("" :: "v"(a01), "v"(a23), "v"(b)); return; }
-                        GPT_MFMA16(acc, a01, a23, b);
+                        if (sn < VAR_CH) b_nxt = *reinterpret_cast<const v4*>(Bs(cur, sn));
+                        if (GPT_ABL == 5) { El<T>::keep(a, b); return; }
+                        El<T>::mfma16(acc, a, b);
                     };
                     // The fill of the next chunk sits INSIDE the active / idle paths, not behind their join: vmcnt counts in
                     // issue order, and behind a join hipcc has to wait for vmcnt(0) — which also waits for the A fragments
                     // the steps just before have requested (a full L2 round trip per sub-chunk); inside the straight-line
-                    // path it waits for the fill's own loads only (vmcnt(4) / vmcnt(12)).
+                    // path it waits for the fill's own loads only.
                     if (active) {
                         step(0); step(1);
                         if (more && w < 4 && GPT_ABL != 4) produce(cur ^ 1, kn);
@@ -417,14 +447,14 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlan pl, cons
                         step(6); step(7);
                     } else {
                         if (more && GPT_ABL != 4) produce(cur ^ 1, kn);
-                        if (sub + 1 < VAR_SUBS) b_nxt = *reinterpret_cast<const d4*>(Bs(cur, (sub + 1) * VAR_SUB));
+                        if (sub + 1 < VAR_SUBS) b_nxt = *reinterpret_cast<const v4*>(Bs(cur, (sub + 1) * VAR_SUB));
                     }
                 }
                 if (GPT_ABL != 1) __syncthreads();
             };
-            for (int ch = 0; ch + 1 < nchunks; ++ch) chunk(std::true_type{}, ch);
-            if (nchunks > 0) chunk(std::false_type{}, nchunks - 1);
-            if (!GEN && GPT_ABL != 3) {
+            for (int ch = ch0; ch + 1 < ch1; ++ch) chunk(std::true_type{}, ch);
+            if (ch1 > ch0) chunk(std::false_type{}, ch1 - 1);
+            if (!GEN && has_diag && GPT_ABL != 3) {
                 // Diagonal tile of a reload sweep, barrier-free: every wave runs its own 16 (g + 1) k-steps with A from
                 // Wf and B straight from the scratch image (both one MFMA block ahead; program order pinned with
                 // sched_barrier so hipcc keeps the loads away from their first use).  No lock-step, so the waves with
@@ -432,186 +462,229 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlan pl, cons
                 // instead of 0.75.
                 const int kd0 = ib * WT_K4;                              // first k-step of the diagonal tile
                 const int limit = 16 * (g + 1);                          // even
-                const d2* ap = wuni + (S_ib + kd0) * STEP_D2;
-                const d2* bp = buni + (size_t)kd0 * 128;
-                auto ldA = [&](d2 (&a)[2], const int k) {
+                const avec* ap = wuni + (S_ib + kd0) * A_STEP;
+                const v4* bp = buni + (size_t)kd0 * 64;
+                auto ldA = [&](AF& a, const int k) {
                     const int kk = k < limit ? k : limit - 1;            // clamped: redundant, in bounds
-                    a[0] = (ap + (size_t)kk * STEP_D2)[wlane]; a[1] = (ap + (size_t)kk * STEP_D2)[wlane + 64];
+                    El<T>::lda(a, ap + (size_t)kk * A_STEP, lane);
                 };
-                auto ldB = [&](d2 (&b)[2], const int k) {
+                auto ldB = [&](v4& b, const int k) {
                     const int kk = k < limit ? k : limit - 1;
-                    b[0] = (bp + (size_t)kk * 128)[blane]; b[1] = (bp + (size_t)kk * 128)[blane + 1];
+                    b = (bp + (size_t)kk * 64)[lane];
                 };
-                d2 a0[2], a1[2], b0[2], b1[2];
+                AF a0, a1;
+                v4 b0, b1;
                 ldA(a0, 0); ldA(a1, 1); ldB(b0, 0);
                 for (int k4 = 0; k4 < limit; k4 += 2) {
                     ldB(b1, k4 + 1);
                     __builtin_amdgcn_sched_barrier(0);
-                    { const d4 bb = d4{b0[0][0], b0[0][1], b0[1][0], b0[1][1]}; GPT_MFMA16(acc, a0[0], a0[1], bb); }
+                    El<T>::mfma16(acc, a0, b0);
                     __builtin_amdgcn_sched_barrier(0);
                     ldA(a0, k4 + 2); ldB(b0, k4 + 2);
                     __builtin_amdgcn_sched_barrier(0);
-                    { const d4 bb = d4{b1[0][0], b1[0][1], b1[1][0], b1[1][1]}; GPT_MFMA16(acc, a1[0], a1[1], bb); }
+                    El<T>::mfma16(acc, a1, b1);
                     __builtin_amdgcn_sched_barrier(0);
                     ldA(a1, k4 + 3);
                 }
             }
-            // i-block finished: fold this wave's 64 rows of V into the per-column sums
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
+            if (vslot >= 0) {
+                // cut sweep: this part's 512 x 64 partial product goes to vslab, [vslot][wave][r*4+t][lane] (k_var_combine)
+                v4* dst = reinterpret_cast<v4*>(vslab) + ((size_t)vslot * 8 + w) * (16 * 64) + lane;
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const double v = acc[r][t][e];
-                        ssq[t] += v * v;
-                        if (CROSS) crs[t] += v * __shfl(v, lane & ~3);
-                    }
+                    for (int t = 0; t < 4; ++t) dst[(r * 4 + t) * 64] = acc[r][t];
+            } else {
+                // whole sweep: fold this wave's 64 rows of V into the per-column sums
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const T v = acc[r][t][e];
+                            ssq[t] += v * v;
+                            if (CROSS) crs[t] += v * __shfl(v, lane & ~3);
+                        }
+            }
         };
 
-        sweep(std::true_type{}, hi - 1);                      // longest sweep first: it covers every source the others need
-        if (hi - 2 >= lo) {
+        if (flags & VI_GEN) {
+            sweep(std::true_type{});
             // every wave's part of the scratch image must have reached L2 before another wave reloads it
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            for (int ib = hi - 2; ib >= lo; --ib) {
-                sweep(std::false_type{}, ib);
-            }
+        } else {
+            sweep(std::false_type{});
         }
 
-        // rows of a column are spread over the 4 lane groups lk = 0..3 and over the 8 waves
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            ssq[t] += __shfl_xor(ssq[t], 16); ssq[t] += __shfl_xor(ssq[t], 32);
-            if (CROSS) { crs[t] += __shfl_xor(crs[t], 16); crs[t] += __shfl_xor(crs[t], 32); }
-        }
-        if (lk == 0) {
+        if (slot >= 0) {
+            // rows of a column are spread over the 4 lane groups lk = 0..3 and over the 8 waves
+            T s2[4], cr[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                red[0][w][16 * t + lc] = ssq[t];
-                red[1][w][16 * t + lc] = CROSS ? crs[t] : 0.0;
+                s2[t] = ssq[t]; cr[t] = crs[t];
+                s2[t] += __shfl_xor(s2[t], 16); s2[t] += __shfl_xor(s2[t], 32);
+                if (CROSS) { cr[t] += __shfl_xor(cr[t], 16); cr[t] += __shfl_xor(cr[t], 32); }
             }
-        }
-        __syncthreads();
-        if (threadIdx.x < VAR_SLOT) {
-            const int which = threadIdx.x >> 6, cl = threadIdx.x & 63;
-            double v = 0.0;
+            if (lk == 0) {
 #pragma unroll
-            for (int ww = 0; ww < 8; ++ww) v += red[which][ww][cl];
-            slab[(size_t)slot * VAR_SLOT + threadIdx.x] = v;
+                for (int t = 0; t < 4; ++t) {
+                    red[0][w][16 * t + lc] = s2[t];
+                    red[1][w][16 * t + lc] = CROSS ? cr[t] : (T)0;
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x < VAR_SLOT) {
+                const int which = threadIdx.x >> 6, cl = threadIdx.x & 63;
+                T v = (T)0;
+#pragma unroll
+                for (int ww = 0; ww < 8; ++ww) v += red[which][ww][cl];
+                slab[(size_t)slot * VAR_SLOT + threadIdx.x] = v;
+            }
         }
     }
 }
 
-// Adds the partial rows of a column block in range order and turns them into outputs.
-template <int NCOMP>
-__global__ __launch_bounds__(64) void k_var_finalize(KernelParams p, VarPlan pl, const double* __restrict__ slab, int64_t M,
-                                                     double* __restrict__ var, double* __restrict__ Jvar,
-                                                     double* __restrict__ dvar) {
-    const int64_t cb = blockIdx.x;
-    const int cl = threadIdx.x;
-    double s2 = 0.0, cr = 0.0;
-    if (cb < pl.nfull) {                                  // handled whole by one workgroup: one slot
-        const double* sl = slab + (size_t)cb * VAR_SLOT;
-        s2 = sl[cl]; cr = sl[VAR_COLS + cl];
-    } else {                                              // tail: add the ranges that touched it, in range order
-        const int64_t cbt = cb - pl.nfull;
-        int64_t pa64 = (cbt * pl.T) * pl.P / pl.U - 2;    // B_p <= U p / P, so this p starts at or before the block
-        if (pa64 < 0) pa64 = 0;
-        if (pa64 > pl.P - 1) pa64 = pl.P - 1;
-        for (int pp = (int)pa64; pp < pl.P; ++pp) {
-            int64_t cbs, cbe; int ibs, ibe;
-            var_boundary(pl, pp, cbs, ibs);
-            if (cbs > cbt) break;
-            var_boundary(pl, pp + 1, cbe, ibe);
-            const int lo = (cbs == cbt) ? ibs : 0;                      // cbs <= cbt here
-            const int hi = (cbe > cbt) ? pl.nbi : ((cbe == cbt) ? ibe : 0);
-            if (lo >= hi) continue;
-            const double* sl = slab + (size_t)(pl.nfull + pp + cbt) * VAR_SLOT;
-            s2 += sl[cl];
-            cr += sl[VAR_COLS + cl];
+// A sweep the work split cut along k: add its parts' partial products in part order, then square / reduce as the
+// kernel's own epilogue does.  One workgroup per cut sweep, same thread -> element map as k_var.
+template <typename T, bool CROSS>
+__global__ __launch_bounds__(512) void k_var_combine(VarPlanDev pl, const T* __restrict__ vslab, T* __restrict__ slab) {
+    typedef typename El<T>::v4 v4;
+    __shared__ T red[2][8][VAR_COLS];
+    const VarSplit sp = pl.splits[blockIdx.x];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lc = lane & 15, lk = lane >> 4;
+    v4 acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = v4{0, 0, 0, 0};
+    for (int v = sp.v_begin; v < sp.v_end; ++v) {
+        const v4* src = reinterpret_cast<const v4*>(vslab) + ((size_t)v * 8 + w) * (16 * 64) + lane;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] += src[i * 64];
+    }
+    T ssq[4] = {0, 0, 0, 0}, crs[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const T v = acc[r * 4 + t][e];
+                ssq[t] += v * v;
+                if (CROSS) crs[t] += v * __shfl(v, lane & ~3);
+            }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        ssq[t] += __shfl_xor(ssq[t], 16); ssq[t] += __shfl_xor(ssq[t], 32);
+        if (CROSS) { crs[t] += __shfl_xor(crs[t], 16); crs[t] += __shfl_xor(crs[t], 32); }
+    }
+    if (lk == 0) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            red[0][w][16 * t + lc] = ssq[t];
+            red[1][w][16 * t + lc] = CROSS ? crs[t] : (T)0;
         }
     }
-    const int D = p.D;
+    __syncthreads();
+    if (threadIdx.x < VAR_SLOT) {
+        const int which = threadIdx.x >> 6, cl = threadIdx.x & 63;
+        T v = (T)0;
+#pragma unroll
+        for (int ww = 0; ww < 8; ++ww) v += red[which][ww][cl];
+        slab[(size_t)sp.slot * VAR_SLOT + threadIdx.x] = v;
+    }
+}
+
+// Adds the partial sums of a (column block, task) in slot order and turns them into outputs:
+// var (M, ntask), Jvar (M, ntask, D), dvar (D, M) (ntask = 1 only).
+template <typename T, int NCOMP>
+__global__ __launch_bounds__(64) void k_var_finalize(KernelParams p, VarPlanDev pl, const T* __restrict__ slab, int64_t M,
+                                                     const double* __restrict__ hdr, T* __restrict__ var,
+                                                     T* __restrict__ Jvar, T* __restrict__ dvar) {
+    const int64_t cb = blockIdx.x;
+    const int cl = threadIdx.x;
+    const int D = p.D, NT = pl.ntask;
     const int64_t col = cb * VAR_COLS + cl;
     const int64_t m = (NCOMP == 1) ? col : ((NCOMP == 4) ? (col >> 2) : (col / D));
     const int cmp = (NCOMP == 1) ? 0 : ((NCOMP == 4) ? (int)(col & 3) : 1 + (int)(col % D));
-    if (m >= M) return;
-    if (cmp == 0) {
-        if (var) { const double v = p.c + p.noise - s2; var[m] = v < 0.0 ? 0.0 : v; }
-    } else {
-        const int d = cmp - 1;
-        if (d < D) {
-            if (Jvar) Jvar[m * D + d] = p.c * p.inv_ls[d] * p.inv_ls[d] - s2;
-            if (dvar) dvar[(int64_t)d * M + m] = -2.0 * cr;
+    for (int task = 0; task < NT; ++task) {
+        T s2 = (T)0, cr = (T)0;
+        int s_begin, s_end;
+        if (cb < pl.nfull) { s_begin = (int)(cb * NT + task); s_end = s_begin + 1; }      // handled whole by one workgroup
+        else {
+            const int64_t e = (cb - pl.nfull) * NT + task;
+            s_begin = pl.fin[2 * e]; s_end = pl.fin[2 * e + 1];
+        }
+        for (int s = s_begin; s < s_end; ++s) {
+            const T* sl = slab + (size_t)s * VAR_SLOT;
+            s2 += sl[cl];
+            cr += sl[VAR_COLS + cl];
+        }
+        if (m >= M) continue;
+        const T c = (T)hdr[16 + task];
+        if (cmp == 0) {
+            if (var) { const T v = c + (T)p.noise - s2; var[m * NT + task] = v < (T)0 ? (T)0 : v; }
+        } else {
+            const int d = cmp - 1;
+            if (d < D) {
+                if (Jvar) Jvar[(m * NT + task) * D + d] = c * (T)(p.inv_ls[d] * p.inv_ls[d]) - s2;
+                if (dvar) dvar[(int64_t)d * M + m] = (T)-2 * cr;
+            }
         }
     }
 }
 
-static int var_workgroups() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-        if (n <= 0) n = 256;
-        const char* e = getenv("GPT_VAR_WGS");
-        if (e && atoi(e) > 0) n = atoi(e);
+template <typename T>
+static void launch_var_t(hipStream_t s, const KernelParams& p, const VarWorkspace& ws, const T* Xs, const T* Wf,
+                         const T* Xq, int64_t M, int ncomp, T* var, T* Jvar, T* dvar, const double* hdr) {
+    const VarPlanDev& pl = ws.plan->d;
+    constexpr size_t lds = var_lds_bytes<T>();
+    static PerDeviceOnce once;
+    if (once.first()) {      // dynamic LDS beyond the default limit is an opt-in per kernel and device
+        const void* fns[] = {reinterpret_cast<const void*>(k_var<T, 1, false, KT_RBF>), reinterpret_cast<const void*>(k_var<T, 4, true, KT_RBF>),
+                             reinterpret_cast<const void*>(k_var<T, 4, false, KT_RBF>), reinterpret_cast<const void*>(k_var<T, 3, false, KT_RBF>),
+                             reinterpret_cast<const void*>(k_var<T, 1, false, KT_MATERN12>),
+                             reinterpret_cast<const void*>(k_var<T, 1, false, KT_MATERN32>), reinterpret_cast<const void*>(k_var<T, 1, false, KT_MATERN52>)};
+        for (const void* f : fns) hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
-    return n;
-}
-
-static VarPlan make_plan(const KernelParams& p, int64_t M, int ncomp) {
-    VarPlan pl;
-    pl.nbi = p.NP / WT;
-    const int cpq = (ncomp == 3) ? p.D : ncomp;          // ncomp 3 = Jacobian variance alone: D columns per query
-    pl.ncb = (M * cpq + VAR_COLS - 1) / VAR_COLS;
-    pl.P = var_workgroups();
-    pl.T = var_cost_prefix(pl.nbi);
-    pl.nfull = pl.ncb / pl.P * pl.P;
-    pl.ncb_t = pl.ncb - pl.nfull;
-    pl.U = pl.ncb_t * pl.T;
-    return pl;
-}
-
-size_t var_slab_doubles(int64_t M, int ncomp) {
-    const int64_t ncb = (M * ncomp + VAR_COLS - 1) / VAR_COLS;
-    return (size_t)(ncb + var_workgroups() + 1) * VAR_SLOT;
-}
-
-size_t var_bscratch_doubles(int NP) { return (size_t)var_workgroups() * (size_t)NP * VAR_COLS; }
-
-void launch_var(hipStream_t s, const KernelParams& p, const double* Xs, const double* Wf,
-                const double* Xq, int64_t M, int ncomp, double* var, double* Jvar, double* dvar, double* slab,
-                double* bscratch) {
-    if (M <= 0) return;
-    const VarPlan pl = make_plan(p, M, ncomp);
-    static bool attr_set = false;
-    if (!attr_set) {      // 128 KiB of dynamic LDS per workgroup
-        const void* fns[] = {reinterpret_cast<const void*>(k_var<1, false, KT_RBF>), reinterpret_cast<const void*>(k_var<4, true, KT_RBF>),
-                             reinterpret_cast<const void*>(k_var<4, false, KT_RBF>), reinterpret_cast<const void*>(k_var<3, false, KT_RBF>),
-                             reinterpret_cast<const void*>(k_var<1, false, KT_MATERN12>),
-                             reinterpret_cast<const void*>(k_var<1, false, KT_MATERN32>), reinterpret_cast<const void*>(k_var<1, false, KT_MATERN52>)};
-        for (const void* f : fns) hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VAR_LDS_BYTES);
-        attr_set = true;
-    }
-    const dim3 grid((unsigned)pl.P), fgrid((unsigned)pl.ncb);
+    T* slab = static_cast<T*>(ws.slab);
+    T* vslab = static_cast<T*>(ws.vslab);
+    T* bscr = static_cast<T*>(ws.bscratch);
+    const dim3 grid((unsigned)pl.P), fgrid((unsigned)pl.ncb), cgrid((unsigned)pl.n_splits);
+#define GPT_KVAR(NC_, CR_, KT_) hipLaunchKernelGGL((k_var<T, NC_, CR_, KT_>), grid, dim3(512), lds, s, p, pl, Xs, Wf, Xq, M, slab, vslab, bscr)
+    bool cross = false;
     if (ncomp == 1) {
         switch (p.ktype) {
-            case KT_MATERN12: hipLaunchKernelGGL((k_var<1, false, KT_MATERN12>), grid, dim3(512), VAR_LDS_BYTES, s, p, pl, Xs, Wf, Xq, M, slab, bscratch); break;
-            case KT_MATERN32: hipLaunchKernelGGL((k_var<1, false, KT_MATERN32>), grid, dim3(512), VAR_LDS_BYTES, s, p, pl, Xs, Wf, Xq, M, slab, bscratch); break;
-            case KT_MATERN52: hipLaunchKernelGGL((k_var<1, false, KT_MATERN52>), grid, dim3(512), VAR_LDS_BYTES, s, p, pl, Xs, Wf, Xq, M, slab, bscratch); break;
-            default: hipLaunchKernelGGL((k_var<1, false, KT_RBF>), grid, dim3(512), VAR_LDS_BYTES, s, p, pl, Xs, Wf, Xq, M, slab, bscratch);
+            case KT_MATERN12: GPT_KVAR(1, false, KT_MATERN12); break;
+            case KT_MATERN32: GPT_KVAR(1, false, KT_MATERN32); break;
+            case KT_MATERN52: GPT_KVAR(1, false, KT_MATERN52); break;
+            default: GPT_KVAR(1, false, KT_RBF);
         }
-        hipLaunchKernelGGL((k_var_finalize<1>), fgrid, dim3(64), 0, s, p, pl, slab, M, var, Jvar, dvar);
-    } else if (ncomp == 3) {      // Jacobian variance alone: three columns per query
-        hipLaunchKernelGGL((k_var<3, false, KT_RBF>), grid, dim3(512), VAR_LDS_BYTES, s, p, pl, Xs, Wf, Xq, M, slab, bscratch);
-        hipLaunchKernelGGL((k_var_finalize<3>), fgrid, dim3(64), 0, s, p, pl, slab, M, var, Jvar, dvar);
-    } else {      // Jacobian variance / d var: RBF only (the API refuses other kernels)
-        if (dvar) hipLaunchKernelGGL((k_var<4, true, KT_RBF>), grid, dim3(512), VAR_LDS_BYTES, s, p, pl, Xs, Wf, Xq, M, slab, bscratch);
-        else hipLaunchKernelGGL((k_var<4, false, KT_RBF>), grid, dim3(512), VAR_LDS_BYTES, s, p, pl, Xs, Wf, Xq, M, slab, bscratch);
-        hipLaunchKernelGGL((k_var_finalize<4>), fgrid, dim3(64), 0, s, p, pl, slab, M, var, Jvar, dvar);
+    } else if (ncomp == 3) {      // Jacobian variance alone: D columns per query
+        GPT_KVAR(3, false, KT_RBF);
+    } else {                      // Jacobian variance / d var: RBF only (the API refuses other kernels)
+        cross = dvar != nullptr;
+        if (cross) GPT_KVAR(4, true, KT_RBF);
+        else GPT_KVAR(4, false, KT_RBF);
     }
+#undef GPT_KVAR
+    if (pl.n_splits > 0) {
+        if (cross) hipLaunchKernelGGL((k_var_combine<T, true>), cgrid, dim3(512), 0, s, pl, vslab, slab);
+        else hipLaunchKernelGGL((k_var_combine<T, false>), cgrid, dim3(512), 0, s, pl, vslab, slab);
+    }
+    if (ncomp == 1) hipLaunchKernelGGL((k_var_finalize<T, 1>), fgrid, dim3(64), 0, s, p, pl, slab, M, hdr, var, Jvar, dvar);
+    else if (ncomp == 3) hipLaunchKernelGGL((k_var_finalize<T, 3>), fgrid, dim3(64), 0, s, p, pl, slab, M, hdr, var, Jvar, dvar);
+    else hipLaunchKernelGGL((k_var_finalize<T, 4>), fgrid, dim3(64), 0, s, p, pl, slab, M, hdr, var, Jvar, dvar);
+}
+
+void launch_var(hipStream_t s, const KernelParams& p, const VarWorkspace& ws, const void* Xs, const void* Wf,
+                const void* Xq, int64_t M, int ncomp, void* var, void* Jvar, void* dvar, const double* hdr) {
+    if (M <= 0 || !ws.plan) return;
+    if (p.dtype == DT_F32)
+        launch_var_t<float>(s, p, ws, (const float*)Xs, (const float*)Wf, (const float*)Xq, M, ncomp, (float*)var, (float*)Jvar, (float*)dvar, hdr);
+    else
+        launch_var_t<double>(s, p, ws, (const double*)Xs, (const double*)Wf, (const double*)Xq, M, ncomp, (double*)var, (double*)Jvar, (double*)dvar, hdr);
 }
 
 }  // namespace gpt

@@ -33,7 +33,7 @@ def wrap_device_bytes(ptr: int, nbytes: int, device):
 
 
 def broadcast_geometry(geom, src=0, group=None):
-    """Broadcast (N, D, O) from `src` (CPU-side object collective; tiny)."""
+    """Broadcast (N, D, O, tasks, element type) from `src` (CPU-side object collective; tiny)."""
     import torch.distributed as dist
     box = [tuple(int(v) for v in geom) if geom is not None else None]
     dist.broadcast_object_list(box, src=src, group=group)
@@ -51,12 +51,12 @@ def broadcast_model(handle, fitted: bool, src=0, group=None, device=None):
         if not fitted:
             raise RuntimeError("broadcast_model: source rank has no fitted model")
         N, D, O, _ = handle.info()
-        geom = (N, D, O)
-    N, D, O = broadcast_geometry(geom, src=src, group=group)
+        geom = (N, D, O) + tuple(handle.model_info())          # + (tasks, element type)
+    N, D, O, n_tasks, dtype = broadcast_geometry(geom, src=src, group=group)
     if rank == src:
         ptr, nbytes = handle.factor_blob()
     else:
-        ptr, nbytes = handle.factor_alloc(N, D, O)
+        ptr, nbytes = handle.factor_alloc(N, D, O, n_tasks, dtype)
     handle.synchronize()                       # fit kernels done before RCCL reads the blob
     dev = device if device is not None else torch.device("cuda", handle.device)
     buf = wrap_device_bytes(ptr, nbytes, dev)

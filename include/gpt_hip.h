@@ -8,13 +8,17 @@
  * call it stands in for; the ctypes binding a maintainer would add is shown in INTEGRATION.md.
  *
  * Conventions
- *   - plain C, no torch / numpy types; all matrices are C-contiguous row-major fp64
+ *   - plain C, no torch / numpy types; all matrices are C-contiguous row-major.  Fit inputs are always fp64;
+ *     queries and outputs of the predict entry points are in the MODEL's element type: fp64 (double) unless the
+ *     model was fitted with GPT_F32 (float) — see gpt_set_dtype / gpt_fit_svgp
  *   - "host" pointers are ordinary process memory, "dev" pointers are HIP device memory on the
  *     handle's device (e.g. torch.Tensor.data_ptr()); the library owns every other allocation
  *   - every function returns 0 on success or a negative GPT_E_* code; gpt_last_error() returns
  *     the message of the last failure on the calling thread
  *   - one handle = one fitted model on one GPU; a handle is not thread-safe
- *   - D (input dims) in 1..3; O (outputs) >= 1; length_scale has 1 (isotropic) or D entries
+ *   - D (input dims) in 1..3 (the reference's transport problems are 2-D and 3-D; its regressor itself is
+ *     dimension-agnostic — a narrowing of the drop-in, refused with GPT_E_ARG); O (outputs) >= 1; length_scale has
+ *     1 (isotropic) or D entries
  */
 #ifndef GPT_HIP_H
 #define GPT_HIP_H
@@ -35,6 +39,13 @@ typedef struct gpt_handle gpt_handle;
 #define GPT_E_ARG (-3)        /* bad argument                                                   */
 #define GPT_E_STATE (-4)      /* model not fitted / factor not committed                        */
 
+/* Element type of a model's prediction side (scaled sources, alpha, packed inverse factor, queries, outputs).
+ * The factorisation always runs in fp64; with GPT_F32 its results are rounded once when the model is packed and the
+ * prediction kernels run on v_mfma_f32_16x16x4_f32 — the arithmetic of the reference's torch SVGP path
+ * (models/torch/stocastic_variational_gaussian_process_derivatives.py computes in torch.float32). */
+#define GPT_F64 0
+#define GPT_F32 1
+
 /* Number of visible HIP devices (0 when no GPU: the Python shim then refuses to run). */
 int gpt_device_count(void);
 /* Text of the last error on this thread ("" if none). */
@@ -50,6 +61,9 @@ void gpt_destroy(gpt_handle* h);
 int gpt_set_stream(gpt_handle* h, void* hip_stream);
 /* Block until the handle's stream is idle. */
 int gpt_synchronize(gpt_handle* h);
+
+/* Element type of the models this handle fits from now on (default GPT_F64). */
+int gpt_set_dtype(gpt_handle* h, int dtype);
 
 /* fit — replaces GaussianProcess.fit (models/gaussian_process.py:25-43) for fixed hyper-
  * parameters: sklearn's K = c*RBF(X/l) + (noise_level + alpha)*I, L = cholesky(K), alpha_ =
@@ -83,28 +97,43 @@ int gpt_fit_noise_matrix(gpt_handle* h, const double* X, const double* Y, int64_
                          const double* length_scale, int n_ls, double constant_value, const double* Sigma,
                          double alpha_jitter, int kernel_type);
 
+/* The whole multi-task model of the reference's SVGP exact conversion in ONE handle — replaces
+ * SVGP.convert_to_exact_gp (models/torch/stocastic_variational_gaussian_process_derivatives.py:72-78) and feeds
+ * posterior_f (:113-129) / posterior_f_prime (:132-153):
+ *   Z (N,D) inducing points; y (T,N) pseudo-targets; Sigma (T,N,N) SPD pseudo-point covariances; outputscale (T);
+ *   length_scale (1 or D, shared by the tasks as in the reference's kernel, batch_shape [1]).
+ * Per task t: K_t = outputscale_t RBF(Z,Z) + Sigma_t + jitter I, W_t = chol(K_t)^-1, alpha_t = K_t^-1 y_t (fp64).
+ * The tasks' factors are stacked into one A operand (each times its outputscale) and share one generated B operand,
+ * so a query pays its exps once, not T times.  Afterwards the predict entry points return, with O = T:
+ *   mean (M,T); var (M,T) = outputscale_t - k*_t^T K_t^-1 k*_t; J (M,T,D); Jvar (M,T,D) = outputscale_t / l_d^2 -
+ *   dk_d^T K_t^-1 dk_d   (the reference takes sqrt of both variances; the caller does).
+ * dtype: GPT_F64 or GPT_F32 (BASELINE configs[4] is fp32).  T <= 32.  Host memory.  GPT_E_NOT_PD if a K_t is not PD. */
+int gpt_fit_svgp(gpt_handle* h, const double* Z, const double* y, const double* Sigma, int64_t N, int D, int T,
+                 const double* length_scale, int n_ls, const double* outputscale, double jitter, int dtype);
+
 /* predict — replaces GaussianProcess.predict (gaussian_process.py:46-55 -> sklearn/_gpr.py:441-494).
  * mean (M,O); var (M,) = max(c + noise_level - |L^-1 k*|^2, 0) (the caller applies sqrt, the
  * tiling over O and the reference's `- sqrt(noise_level)` quirk).  var may be NULL. Host memory. */
-int gpt_predict(gpt_handle* h, const double* Xq, int64_t M, double* mean, double* var);
+int gpt_predict(gpt_handle* h, const void* Xq, int64_t M, void* mean, void* var);
 
 /* derivative — replaces GaussianProcess.derivative (gaussian_process.py:63-102).
  * J (M,O,D) with J[m,o,d] = d mean_o / d x_d; Jvar (M,D) = c/l_d^2 - dk_d^T K^-1 dk_d (the
  * reference tiles it over O).  Jvar may be NULL.  Host memory. */
-int gpt_derivative(gpt_handle* h, const double* Xq, int64_t M, double* J, double* Jvar);
+int gpt_derivative(gpt_handle* h, const void* Xq, int64_t M, void* J, void* Jvar);
 
 /* derivative_of_variance — replaces GaussianProcess.derivative_of_variance
  * (gaussian_process.py:104-126).  g is (D,M).  Host memory. */
-int gpt_dvariance(gpt_handle* h, const double* Xq, int64_t M, double* g);
+int gpt_dvariance(gpt_handle* h, const void* Xq, int64_t M, void* g);
 
 /* Fused metric path: any of mean (M,O) / var (M,) / J (M,O,D) / Jvar (M,D) / dvar (D,M) may be
- * NULL.  Host memory (pageable is fine); queries are streamed through the device in chunks of 131072, the outputs of
+ * NULL (multi-task model: var (M,T), Jvar (M,T,D), no dvar).  Buffers in the model's element type.
+ * Host memory (pageable is fine); queries are streamed through the device in chunks of 131072, the outputs of
  * one chunk leaving on a copy stream while the next chunk computes.  Returns when every output is in place. */
-int gpt_predict_all(gpt_handle* h, const double* Xq, int64_t M, double* mean, double* var,
-                    double* J, double* Jvar, double* dvar);
+int gpt_predict_all(gpt_handle* h, const void* Xq, int64_t M, void* mean, void* var,
+                    void* J, void* Jvar, void* dvar);
 /* Same with every pointer in device memory; asynchronous on the handle's stream. */
-int gpt_predict_all_dev(gpt_handle* h, const double* Xq_dev, int64_t M, double* mean_dev,
-                        double* var_dev, double* J_dev, double* Jvar_dev, double* dvar_dev);
+int gpt_predict_all_dev(gpt_handle* h, const void* Xq_dev, int64_t M, void* mean_dev,
+                        void* var_dev, void* J_dev, void* Jvar_dev, void* dvar_dev);
 /* (new) Allocates the library-owned scratch a gpt_predict_all_dev call with M queries will use (grow-only; with
  * jacobian_variance != 0 for the 4-column path), so that the first such call does not allocate. */
 int gpt_reserve(gpt_handle* h, int64_t M, int jacobian_variance);
@@ -138,10 +167,15 @@ int gpt_lml_gradient(gpt_handle* h, double* lml, double* grad);
  *   others   : gpt_factor_commit(h)                                (parses the header)           */
 int gpt_factor_blob(gpt_handle* h, void** dev_ptr, size_t* bytes);
 int gpt_factor_alloc(gpt_handle* h, int64_t N, int D, int O, void** dev_ptr, size_t* bytes);
+/* The same for any model: n_tasks = 1 and GPT_F64 for gpt_fit*, (T, dtype) for gpt_fit_svgp — see gpt_model_info. */
+int gpt_factor_alloc_model(gpt_handle* h, int64_t N, int D, int O, int n_tasks, int dtype, void** dev_ptr, size_t* bytes);
 int gpt_factor_commit(gpt_handle* h);
 
 /* Model geometry of a fitted / committed handle. */
 int gpt_info(gpt_handle* h, int64_t* N, int* D, int* O, int64_t* N_padded);
+
+/* Stacked tasks (1 unless fitted by gpt_fit_svgp) and element type (GPT_F64 / GPT_F32) of the model. */
+int gpt_model_info(gpt_handle* h, int* n_tasks, int* dtype);
 
 /* Per-phase device times of the last gpt_fit in milliseconds (hipEvent):
  * [0] total [1] gram [2] cholesky [3] triangular inverse [4] alpha [5] pack.  n <= 6. */
@@ -153,6 +187,14 @@ int gpt_fit_timings(gpt_handle* h, double* ms_out, int n);
  * ms_out[1] = variance (MFMA) kernel; 0 for a kernel that was not launched. */
 int gpt_set_profiling(gpt_handle* h, int enable);
 int gpt_predict_timings(gpt_handle* h, double* ms_out);
+
+/* Test hook (host only, no GPU): the work decomposition of the variance kernel for a launch of n_columns kernel
+ * columns over n_iblocks 512-row blocks x n_tasks tasks on n_workgroups workgroups (csrc/gpt_plan.h).
+ * order: -1 automatic, 0 block-major, 1 sweep-major.  counts[8] = {items, cut sweeps, slab slots, partial-product
+ * slots, column blocks, blocks in whole rounds, tail (block, task) pairs, order used}; the arrays may be NULL (first
+ * call) or hold item_begin[n_workgroups + 1], items[counts[0]][8], fin[counts[6]][2], splits[counts[1]][3]. */
+int gpt_debug_var_plan(int64_t n_columns, int n_iblocks, int n_tasks, int n_workgroups, int order, int64_t* counts,
+                       int* item_begin, int* items, int* fin, int* splits);
 
 #ifdef __cplusplus
 }

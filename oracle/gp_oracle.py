@@ -383,6 +383,50 @@ def svgp_exact_oracle(x, Z, Sigma, y, outputscale, lengthscale):
     return mean, std, J, Js
 
 
+def svgp_exact_oracle_fast(x, Z, Sigma, y, outputscale, lengthscale, dtype=np.float64):
+    """Same quantities as svgp_exact_oracle with the quadratic forms as matrix products (BLAS) — for Z in the
+    thousands — and in the arithmetic `dtype`: float32 restates what the reference computes (it casts inputs with
+    `.float()` and inverts K_uu + Sigma in fp32, :72-78), float64 is the yardstick.  ref lines as above."""
+    f = np.dtype(dtype).type
+    x = np.asarray(x, dtype); Z = np.asarray(Z, dtype); Sigma = np.asarray(Sigma, dtype)
+    ls = np.broadcast_to(np.atleast_1d(np.asarray(lengthscale, dtype)), (Z.shape[1],))
+    T = Sigma.shape[0]
+    M, D = x.shape
+
+    def sq(a, b):
+        return np.maximum((a * a).sum(1)[:, None] + (b * b).sum(1)[None, :] - f(2) * (a @ b.T), f(0))
+    R = np.exp(f(-0.5) * sq(x / ls, Z / ls))
+    Ruu = np.exp(f(-0.5) * sq(Z / ls, Z / ls))
+    mean = np.empty((M, T), dtype); std = np.empty((M, T), dtype); J = np.empty((M, T, D), dtype); Js = np.empty((M, T, D), dtype)
+    for t in range(T):
+        os_t = f(outputscale[t])
+        Kinv = np.linalg.inv(os_t * Ruu + Sigma[t])
+        a = Kinv @ np.reshape(np.asarray(y[t], dtype), (-1,))
+        ks = os_t * R
+        mean[:, t] = ks @ a
+        std[:, t] = np.sqrt(np.maximum(os_t - ((ks @ Kinv) * ks).sum(1), f(0)))
+        for d in range(D):
+            dk = (Z[None, :, d] - x[:, None, d]) / ls[d] ** 2 * ks
+            J[:, t, d] = dk @ a
+            Js[:, t, d] = np.sqrt(np.maximum(os_t / ls[d] ** 2 - ((dk @ Kinv) * dk).sum(1), f(0)))
+    return mean, std, J, Js
+
+
+def svgp_synthetic_problem(Zn, M, T=3, D=3, seed=0, qseed=1):
+    """SURVEY §8d cfg5 inputs: inducing points U[0,1]^D, Sigma_pseudo = A A^T / Z + 1e-3 I (A ~ N(0,1)), y_pseudo ~
+    N(0,1), outputscale 1, length-scale 0.2, queries U[-0.1,1.1]^D.  Returns Z, Sigma (T,Z,Z), y (T,Z),
+    outputscale (T,), lengthscale (D,), Xq."""
+    rng = np.random.default_rng(seed)
+    Z = rng.uniform(0, 1, (Zn, D))
+    Sigma = np.empty((T, Zn, Zn))
+    for t in range(T):
+        A = rng.standard_normal((Zn, Zn))
+        Sigma[t] = A @ A.T / Zn + 1e-3 * np.eye(Zn)
+    y = rng.standard_normal((T, Zn))
+    Xq = np.random.default_rng(qseed).uniform(-0.1, 1.1, (M, D))
+    return Z, Sigma, y, np.ones(T), np.full(D, 0.2), Xq
+
+
 def synthetic_problem(N, M, D=3, seed=0, qseed=1):
     """SURVEY §8d synthetic inputs (identical for CPU and GPU)."""
     rng = np.random.default_rng(seed)

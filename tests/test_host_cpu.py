@@ -48,7 +48,10 @@ def test_product_package_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
     bench = open(os.path.join(ROOT, "bench.py")).read()
-    assert len(re.findall(r"from oracle", bench)) == 1      # only inside cpu_baseline()
+    # only inside the CPU-baseline legs: every function body that imports the oracle is a *cpu_baseline function
+    for m in re.finditer(r"from oracle|import oracle", bench):
+        owner = re.findall(r"^def (\w+)\(", bench[:m.start()], flags=re.M)[-1]
+        assert owner.endswith("cpu_baseline"), owner
 
 
 def test_affine_transform_matches_golden():
@@ -183,3 +186,151 @@ def test_two_rank_gloo_shard_and_gather():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res == [(0, (8192, 3, 3), True), (1, (8192, 3, 3), True)]
+
+
+def _run_bench(*argv, env_extra=None):
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=env, capture_output=True,
+                          text=True, timeout=300)
+
+
+def test_bench_launcher_starts_its_own_ranks():
+    """`python bench.py --gpus 2` (the driver's command shape, no torch.distributed environment) must start two
+    ranks itself and relay ONE JSON line; --dry-run keeps the ranks on gloo / CPU."""
+    import json
+    r = _run_bench("--gpus", "2", "--steps", "2", "--warmup", "0", "--dry-run")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["steps"] == 2
+
+
+def test_bench_launcher_reports_a_failed_rank():
+    """A rank that dies must not leave the launcher (or the other rank) hanging, and the exit code is not 0."""
+    r = _run_bench("--gpus", "2", "--steps", "1", "--dry-run", env_extra={"GPT_BENCH_DRY_FAIL_RANK": "1"})
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_launcher_does_not_touch_the_gpu_stack():
+    """The launcher branch must run before torch / the HIP library are imported (a process that has initialised
+    the GPU must never start or become the ranks)."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    main = src[src.index("def main():"):]
+    assert main.index("launch_ranks(args") < main.index("import torch")
+    launcher = src[src.index("def launch_ranks"):src.index("def dry_run")]
+    assert "import torch" not in launcher and "_lib" not in launcher and "os.exec" not in src
+
+
+VI_GEN, VI_FIRST, VI_ZERO = 1, 2, 4
+
+
+def _check_var_plan(cols, nbi, nt, P, order):
+    """Replays the item lists of csrc/gpt_plan.h the way k_var executes them and checks what the kernel relies on."""
+    from collections import defaultdict
+    from gaussian_process_transportation_amd import _lib
+    pl = _lib.debug_var_plan(cols, nbi, nt, P, order)
+    ncb, nfull = pl["ncb"], pl["nfull"]
+    assert ncb == -(-cols // 64) and nfull == ncb // P * P
+    ncb_t = ncb - nfull
+    cover = np.zeros((max(ncb_t, 1), nt, nbi, nbi), dtype=np.int64)
+    slot_sweeps = {}                      # slab slot -> [(cb, task, ib)] folded into it
+    vslot_part = {}                       # vslab slot -> (cb, task, ib, k_lo, k_hi)
+    cost = np.zeros(P)
+    ib_ = pl["item_begin"]
+    assert ib_[0] == 0 and ib_[-1] == pl["n_items"] and np.all(np.diff(ib_) >= 0)
+    for p in range(P):
+        cur_cb, generated, running = None, set(), None
+        for cb, task, ib, k_lo, k_hi, flags, slot, vslot in pl["items"][ib_[p]:ib_[p + 1]]:
+            assert nfull <= cb < ncb and 0 <= task < nt and 0 <= ib < nbi and 0 <= k_lo < k_hi <= ib + 1
+            if cb != cur_cb:
+                assert flags & VI_FIRST, "a new column block must drop the previous scratch image"
+                cur_cb, generated = cb, set()
+            tiles = set(range(k_lo, k_hi))
+            if flags & VI_GEN:
+                generated |= tiles
+            else:
+                assert tiles <= generated, "reload of B fragments this workgroup never generated for this block"
+            cover[cb - nfull, task, ib, k_lo:k_hi] += 1
+            cost[p] += 128 * (min(k_hi, ib) - k_lo) + (72 if k_hi == ib + 1 else 0)
+            if vslot >= 0:
+                assert slot < 0 and vslot not in vslot_part
+                vslot_part[vslot] = (cb, task, ib, k_lo, k_hi)
+            else:
+                assert (k_lo, k_hi) == (0, ib + 1), "only whole sweeps may be folded into column sums"
+                if flags & VI_ZERO:
+                    assert not running, "column sums dropped without a flush"
+                    running = []
+                assert running is not None, "accumulating onto sums that were already flushed"
+                assert all((c, t) == (cb, task) for c, t, _ in running)
+                running.append((cb, task, ib))
+                if slot >= 0:
+                    assert slot not in slot_sweeps
+                    slot_sweeps[slot] = running
+                    running = None
+        assert not running, "workgroup ends with unflushed column sums"
+    if ncb_t:
+        want = np.tril(np.ones((nbi, nbi), dtype=np.int64))[None, None]          # [ib][k]: k <= ib
+        assert np.array_equal(cover, np.broadcast_to(want, cover.shape)), "a tile is missing or computed twice"
+    assert sorted(vslot_part) == list(range(pl["n_vslots"]))
+    for v0, v1, slot in pl["splits"]:
+        parts = [vslot_part[v] for v in range(v0, v1)]
+        assert len(parts) >= 2 and len({pp[:3] for pp in parts}) == 1
+        assert parts[0][3] == 0 and parts[-1][4] == parts[0][2] + 1
+        assert all(a[4] == b[3] for a, b in zip(parts, parts[1:])), "parts of a cut sweep must tile its k range in order"
+        assert slot not in slot_sweeps
+        slot_sweeps[slot] = [parts[0][:3]]
+    assert sorted(slot_sweeps) == list(range(nfull * nt, pl["n_slots"]))
+    assert len(pl["fin"]) == ncb_t * nt
+    for e, (b, en) in enumerate(pl["fin"]):
+        cbt, task = divmod(e, nt)
+        got = sorted(s for sl in range(b, en) for s in slot_sweeps[sl])
+        assert got == [(nfull + cbt, task, ib) for ib in range(nbi)], "finalize must see every i-block of a (block, task) once"
+    return pl, cost
+
+
+@pytest.mark.parametrize("cols,nbi,nt,P", [(64, 1, 1, 256), (460, 5, 1, 256), (1000, 16, 1, 256), (4 * 4096, 16, 1, 256),
+                                           (500_000, 16, 1, 256), (4 * 500_000, 16, 1, 256), (4_000_000, 4, 3, 256),
+                                           (3 * 700, 2, 3, 256), (300, 3, 2, 7), (16384, 16, 1, 256), (16384 + 64, 16, 1, 256)])
+@pytest.mark.parametrize("order", [-1, 0, 1])
+def test_variance_work_plan_is_a_partition(cols, nbi, nt, P, order):
+    pl, cost = _check_var_plan(cols, nbi, nt, P, order)
+    busy = cost[cost > 0]
+    if len(busy) == P and pl["nfull"] == 0:               # every workgroup has work: shares within a tile of each other
+        assert busy.max() - busy.min() <= 2 * 128 + 72
+
+
+def test_variance_work_plan_random_shapes():
+    rng = np.random.default_rng(5)
+    for _ in range(60):
+        P = int(rng.choice([1, 3, 8, 64, 256, 304]))
+        nbi = int(rng.integers(1, 20))
+        nt = int(rng.choice([1, 1, 2, 3, 5]))
+        cols = int(rng.integers(1, 64 * 3 * P))
+        _check_var_plan(cols, nbi, nt, P, int(rng.integers(-1, 2)))
+
+
+def test_host_orchestration_under_sanitizers():
+    """the host side of the C ABI is built with -fsanitize=address,undefined (g++, `make host-asan`, inert
+    stand-ins for the HIP runtime and the kernels in csrc/host_stub/) and driven through its argument checks, state
+    machine, staging / hand-off copies and variance work plans (tests/asan_driver.py).  GPU sanitizers are not available
+    on the pool; this is the CPU-side half."""
+    import shutil
+    import subprocess
+    import sys
+    csrc = os.path.join(ROOT, "gaussian_process_transportation_amd", "csrc")
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    subprocess.run(["make", "-C", csrc, "host-asan"], check=True, capture_output=True)
+    libasan = subprocess.run(["g++", "-print-file-name=libasan.so"], check=True, capture_output=True, text=True).stdout.strip()
+    env = dict(os.environ, LD_PRELOAD=libasan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:exitcode=23",
+               UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1", GPT_HIP_LIB=os.path.join(csrc, "build", "libgpt_host_asan.so"),
+               PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "asan_driver.py")], env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0 and "ASAN_DRIVER_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-4000:])
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-4000:]
