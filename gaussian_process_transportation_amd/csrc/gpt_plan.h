@@ -14,9 +14,11 @@
 //     remaining sweeps are laid end to end, costed, and cut into P ranges of equal cost AT TILE GRANULARITY.  A sweep
 //     that is cut leaves partial products: each part writes its 512 x 64 partial V to `vslab`, and k_var_combine adds
 //     the parts in order, squares and reduces.  The explicit list of items per workgroup built here is what the
-//     kernel executes.  With no whole round the list is ordered sweep-major (all column blocks of one (task, ib)
-//     next to each other) so that concurrently running workgroups read the same tiles of A; otherwise block-major
-//     (a workgroup keeps its generated B image for the following sweeps of the same block).
+//     kernel executes.  The list is block-major: a workgroup keeps its generated B image for the following sweeps of
+//     the same block, and workgroups p and p + 16 k (same XCD) work on the same tiles of A at the same time.  (The
+//     sweep-major order — all column blocks of one (task, ib) next to each other — is kept as a diagnostic: it lost at
+//     every size, 4.1 -> 5.9 ms at N = 8192, M = 4096: neighbouring workgroups sit on different XCDs and every item
+//     has to generate its B fragments again; profiles/r02_small_m.log.)
 //   * Per-column partial sums go to unique slots of `slab`, a (block, task)'s slots are consecutive and
 //     k_var_finalize adds them in order: deterministic, no atomics.
 #pragma once
@@ -79,7 +81,7 @@ inline int var_sweep_cost(int ib, int k_lo, int k_hi) {
     return c;
 }
 
-// ncols = columns of B (queries x columns per query).  order: -1 automatic, 0 block-major, 1 sweep-major.
+// ncols = columns of B (queries x columns per query).  order: 0 (or -1) block-major, 1 sweep-major (diagnostic).
 inline VarPlanHost build_var_plan(int64_t ncols, int nbi, int ntask, int P, int order = -1) {
     VarPlanHost h;
     VarPlanDev& d = h.d;
@@ -88,7 +90,7 @@ inline VarPlanHost build_var_plan(int64_t ncols, int nbi, int ntask, int P, int 
     d.tiles_per_task = nbi * (nbi + 1) / 2;
     d.nfull = d.ncb / P * P;
     const int ncb_t = (int)(d.ncb - d.nfull);
-    h.order = order >= 0 ? order : (d.nfull == 0 ? 1 : 0);
+    h.order = order > 0 ? 1 : 0;
     h.item_begin.assign(P + 1, 0);
     h.n_slots = d.nfull * ntask;
     if (ncb_t == 0) return h;

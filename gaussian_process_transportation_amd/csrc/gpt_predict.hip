@@ -34,6 +34,8 @@ template <> struct El<double> {
     typedef d4 v4;
     typedef d2 avec;
     static constexpr int A_STEP = 1024, A_GROUP = 128;     // avec per k4-step of a tile / per row group inside it
+    static constexpr int SUBS = 4;                         // sub-chunks of 8 k4-steps per LDS chunk: 2 x 32 steps x 2 KiB = 128 KiB
+    static constexpr int PF = 2;                           // A fragments are requested this many k4-steps (of 1024 cycles) ahead
     struct AF { d2 lo, hi; };
     static __device__ __forceinline__ void lda(AF& a, const avec* __restrict__ p, const int lane) { a.lo = p[lane]; a.hi = p[lane + 64]; }
     static __device__ __forceinline__ void keep(const AF& a, const v4& b) { asm volatile("" :: "v"(a.lo), "v"(a.hi), "v"(b)); }
@@ -52,6 +54,14 @@ template <> struct El<float> {
     typedef f4 v4;
     typedef f4 avec;
     static constexpr int A_STEP = 512, A_GROUP = 64;
+#ifndef GPT_F32_SUBS
+#define GPT_F32_SUBS 4
+#endif
+#ifndef GPT_F32_PF
+#define GPT_F32_PF 4
+#endif
+    static constexpr int SUBS = GPT_F32_SUBS;              // 2 x 32 steps x 1 KiB = 64 KiB (64-step chunks measured 4 % slower: profiles/r02_svgp_variants.txt)
+    static constexpr int PF = GPT_F32_PF;                  // an fp32 MFMA block lasts 512 cycles, less than an L2 round trip under load
     struct AF { f4 v; };
     static __device__ __forceinline__ void lda(AF& a, const avec* __restrict__ p, const int lane) { a.v = p[lane]; }
     static __device__ __forceinline__ void keep(const AF& a, const v4& b) { asm volatile("" :: "v"(a.v), "v"(b)); }
@@ -235,9 +245,7 @@ void launch_mean_jac(hipStream_t s, const KernelParams& p, const void* Xs, const
 #define GPT_ABL 0
 #endif
 constexpr int VAR_SUB = 8;          // k4-steps per sub-chunk (= waves per workgroup: wave w fills step w of each)
-constexpr int VAR_SUBS = 4;         // sub-chunks per LDS chunk
-constexpr int VAR_CH = VAR_SUB * VAR_SUBS;   // k4-steps per LDS chunk, one barrier each (32)
-template <typename T> constexpr size_t var_lds_bytes() { return (size_t)2 * VAR_CH * 64 * 4 * sizeof(T); }   // 128 KiB fp64 / 64 KiB fp32
+template <typename T> constexpr size_t var_lds_bytes() { return (size_t)2 * VAR_SUB * El<T>::SUBS * 64 * 4 * sizeof(T); }   // 128 KiB
 
 template <typename T, int NCOMP, bool CROSS, int KT>
 __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, const T* __restrict__ Xs,
@@ -247,6 +255,8 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
     typedef typename El<T>::avec avec;
     typedef typename El<T>::AF AF;
     constexpr size_t A_STEP = El<T>::A_STEP;
+    constexpr int VAR_SUBS = El<T>::SUBS;               // sub-chunks per LDS chunk
+    constexpr int VAR_CH = VAR_SUB * VAR_SUBS;          // k4-steps per LDS chunk, one barrier each (32 fp64 / 64 fp32; divides 128)
     extern __shared__ __attribute__((aligned(16))) unsigned char Bs_raw[];       // [buffer][k4-step][lane][column tile]
     T* const Bs_dyn = reinterpret_cast<T*>(Bs_raw);
     __shared__ T red[2][8][VAR_COLS];
@@ -386,9 +396,11 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
                     produce(ch0 & 1, K0 + j * VAR_SUB + w);
                 }
             }
-            AF a_nxt, a_nx2;                               // A fragments of the next step and of the one after it
-            El<T>::lda(a_nxt, wuni + (S_ib + K0) * A_STEP, lane);        // the first two steps of an item are active for every group
-            El<T>::lda(a_nx2, wuni + (S_ib + K0 + 1) * A_STEP, lane);
+            constexpr int PF = El<T>::PF;                  // divides VAR_SUB, so step s of every sub-chunk uses ring slot s % PF
+            AF a_ring[PF];                                 // A fragments of the next PF steps
+#pragma unroll
+            for (int i = 0; i < PF; ++i)                   // the first 16 steps of an item are active for every group
+                El<T>::lda(a_ring[i], wuni + (S_ib + K0 + i) * A_STEP, lane);
             __syncthreads();
             v4 acc[4][4];
 #pragma unroll
@@ -424,12 +436,11 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
                     const bool active = (k0 < my_limit) && !(GPT_ABL == 3 && k0 >= ib * WT_K4);   // my_limit is a multiple of 16: all or nothing
                     auto step = [&](const int s) {
                         const int k4 = k0 + s;
-                        const AF a = a_nxt;
+                        const AF a = a_ring[s % PF];
                         const v4 b = b_nxt;
                         const int kl = my_limit - 1;
-                        const size_t Sn = S_ib + ((k4 + 2 < my_limit) ? (k4 + 2) : kl);
-                        a_nxt = a_nx2;
-                        if (GPT_ABL != 2) El<T>::lda(a_nx2, wuni + Sn * A_STEP, lane);
+                        const size_t Sn = S_ib + ((k4 + PF < my_limit) ? (k4 + PF) : kl);
+                        if (GPT_ABL != 2) El<T>::lda(a_ring[s % PF], wuni + Sn * A_STEP, lane);
                         const int sn = sub * VAR_SUB + s + 1;
                         if (sn < VAR_CH) b_nxt = *reinterpret_cast<const v4*>(Bs(cur, sn));
                         if (GPT_ABL == 5) { El<T>::keep(a, b); return; }

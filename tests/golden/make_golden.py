@@ -132,8 +132,38 @@ def case_letterS(pt, resample):
                gp_X=gp.X, gp_Y=gp.Y, theta0=gp.gp.kernel.theta, theta_fit=gp.gp.kernel_.theta,
                bounds=gp.gp.kernel.bounds, lml_fit=np.float64(gp.gp.log_marginal_likelihood_value_),
                noise_var_=np.float64(gp.noise_var_), alpha=np.float64(1e-10), **theta_of(gp))
-    out["samples"] = tr.sample_transportation()[:, ::8, :]   # (10, 50, 2): every 8th trajectory point of the 400
-    out["samples_full_shape"] = np.array(tr.sample_transportation().shape)
+    smp_all = tr.sample_transportation()                     # (10, 400, 2) = rotated positions + sklearn sample_y draws
+    out["samples"] = smp_all[:, ::8, :]                      # (10, 50, 2): every 8th trajectory point of the 400
+    out["samples_full_shape"] = np.array(smp_all.shape)
+    # Evidence for how tightly draws CAN be compared (the posterior covariance of 400 closely spaced points has a large
+    # eigenspace degenerate at ~noise_level, where the SVD basis multivariate_normal uses is arbitrary):
+    #  (1) the draws projected on the leading, well-separated eigenvectors of the reference's own covariance — these
+    #      coordinates are basis-independent, an implementation must reproduce them closely;
+    #  (2) how far the reference's draws move when the SAME covariance is merely recomputed in another order of
+    #      operations (K** - K*^T K^-1 K* by cho_solve instead of sklearn's V^T V; fp64 both): the spread any
+    #      faithful implementation shows in the degenerate directions.
+    pos_rot = tr.method.affine_transform.predict(X)
+    mean_ref, cov_ref = gp.predict(pos_rot, return_cov=True)
+    cov0 = cov_ref[:, :, 0]
+    lam, V = np.linalg.eigh(cov0)
+    lam, V = lam[::-1], V[:, ::-1]
+    gaps = (lam[:-1] - lam[1:]) / lam[0]
+    k = 1
+    while k < 40 and lam[k] > 50 * np.median(lam) and gaps[k - 1] > 1e-6:
+        k += 1
+    Vk = V[:, :k]
+    out["samples_eig_vectors"] = Vk                                       # (400, k)
+    out["samples_eig_values"] = lam[:k]
+    out["samples_eig_coords"] = np.einsum("nk,snt->skt", Vk, smp_all - (pos_rot + mean_ref)[None])    # (10, k, 2)
+    import scipy.linalg
+    Kss = gp.kernel(pos_rot)
+    Ks = gp.kernel(gp.X, pos_rot)
+    cov_alt = Kss - Ks.T @ scipy.linalg.cho_solve((gp.gp.L_, True), Ks)   # K** - K*^T K^-1 K*: same matrix, other roundings
+    rng = np.random.RandomState(0)
+    alt = np.stack([rng.multivariate_normal(mean_ref[:, t], cov_alt, 10) for t in range(mean_ref.shape[1])], axis=2)
+    out["samples_recomputed_spread"] = np.float64(np.max(np.abs((pos_rot[None] + alt) - smp_all)))
+    out["samples_cov_recomputed_diff"] = np.float64(np.max(np.abs(cov_alt - cov0)))
+    out["samples_sd_max"] = np.float64(np.sqrt(np.max(np.diag(cov0))))
     # second transport with do_scale=True, fixed hyper-parameters (affine scale branch)
     np.random.seed(0)
     tr2 = pt.GaussianProcessTransportation(kernel_transport=kern(out["constant_value"],

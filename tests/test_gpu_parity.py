@@ -133,12 +133,18 @@ def test_letterS_transport_fixed_theta():
     assert tr.training_traj_old is g["demo"]
     smp = tr.sample_transportation()
     assert smp.shape == tuple(g["samples_full_shape"])
-    # 400 closely spaced points under a smooth kernel: the posterior covariance has a large eigenspace
-    # degenerate at ~noise_level, where the SVD basis used by multivariate_normal is arbitrary, so draws
-    # differ between implementations by O(sqrt(noise_level)) there (the well-conditioned N=64 case above is
-    # held to 1e-4).  Here: same shape, and every draw within 6 posterior standard deviations of sklearn's.
-    sd = np.sqrt(np.maximum(np.diag(tr.method.delta_map.predict(tr.method.affine_transform.predict(g["demo"]),
-                                                               return_cov=True)[1][:, :, 0]), 0))[::8]
+    # 400 closely spaced points under a smooth kernel: the posterior covariance has a large eigenspace degenerate at
+    # ~noise_level, where the SVD basis used by multivariate_normal is arbitrary.  The golden file carries the evidence
+    # (tests/golden/make_golden.py:case_letterS): recomputing the reference's OWN covariance in another order of
+    # operations (it changes by 1.1e-13) moves the reference's own draws by up to 0.57 (`samples_recomputed_spread`).
+    # So (1) the part of a draw that is basis-independent — its coordinates on the 29 leading, well-separated
+    # eigenvectors of the reference covariance — is held to 1e-6, and (2) the rest stays inside the posterior band.
+    pos_rot = tr.method.affine_transform.predict(g["demo"])
+    mean_rot, cov = tr.method.delta_map.predict(pos_rot, return_cov=True)
+    coords = np.einsum("nk,snt->skt", g["samples_eig_vectors"], smp - (pos_rot + mean_rot)[None])
+    assert_parity(coords, g["samples_eig_coords"], 1e-6, "draws on the leading eigenvectors")
+    assert float(g["samples_recomputed_spread"]) > 0.1       # the reference is no closer to itself than this
+    sd = np.sqrt(np.maximum(np.diag(cov[:, :, 0]), 0))[::8]
     assert np.all(np.abs(smp[:, ::8, :] - g["samples"]) <= 6 * np.sqrt(2) * sd[None, :, None] + 1e-9)
     tr2 = _transport(g, do_scale=True)
     assert float(tr2.method.affine_transform.scale) == pytest.approx(float(g["scale2"]), rel=1e-12)
@@ -353,7 +359,12 @@ def test_lml_value_and_gradient_vs_sklearn(name):
 
 def test_letterS_with_optimizer_matches_reference_fit():
     """Config 1 end to end with the reference's default optimizer: same L-BFGS-B driver and RNG protocol as
-    sklearn, objective on the GPU.  Tolerance 1e-4: limited by the optimizer's own stopping tolerance."""
+    sklearn, objective on the GPU.  What is asserted: (1) the optimum is as good as sklearn's (LML not lower beyond
+    1e-8 relative), (2) theta agrees to 1e-4 — the optimizer's own stopping tolerance, two runs of L-BFGS-B stop at
+    slightly different points of a flat optimum — and (3) the outputs differ from the reference's by no more than what
+    that difference in theta explains: the same GPU path refitted at the REFERENCE's theta reproduces the golden
+    outputs to 1e-5 (test_letterS_transport_fixed_theta), so |out(theta_gpu) - golden| must be within
+    |out(theta_gpu) - out(theta_ref)| + 1e-5 of the array scale."""
     from gaussian_process_transportation_amd import GaussianProcessTransportation
     g = load_golden("letterS_2d")
     np.random.seed(0)
@@ -363,12 +374,20 @@ def test_letterS_with_optimizer_matches_reference_fit():
     tr.fit_transportation(do_scale=False, do_rotation=True)
     tr.apply_transportation()
     gp = tr.method.delta_map
-    assert gp.gp.log_marginal_likelihood_value_ == pytest.approx(float(g["lml_fit"]), rel=1e-6)
+    lml_ref = float(g["lml_fit"])
+    assert gp.gp.log_marginal_likelihood_value_ >= lml_ref - 1e-8 * abs(lml_ref)
+    assert gp.gp.log_marginal_likelihood_value_ == pytest.approx(lml_ref, rel=1e-6)
     assert_parity(np.asarray(gp.kernel.theta), g["theta_fit"], 1e-4, "fitted theta")
-    assert_parity(tr.training_traj, g["traj"], 1e-4, "traj")
-    assert_parity(tr.std, g["std"], 1e-3, "std")
-    assert_parity(tr.training_delta, g["vel"], 1e-4, "vel")
-    assert_parity(tr.var_vel_transported, g["var_vel"], 1e-3, "var_vel")
+    at_ref = _transport(g)                                   # same path, hyper-parameters fixed at the reference's optimum
+    for name, got, fixed, ref in (("traj", tr.training_traj, at_ref.training_traj, g["traj"]), ("std", tr.std, at_ref.std, g["std"]),
+                                  ("vel", tr.training_delta, at_ref.training_delta, g["vel"]),
+                                  ("var_vel", tr.var_vel_transported, at_ref.var_vel_transported, g["var_vel"])):
+        scale = np.max(np.abs(ref))
+        explained = np.max(np.abs(got - fixed)) / scale
+        err = np.max(np.abs(got - ref)) / scale
+        print(f"letter-S optimizer {name}: vs golden {err:.2e}, explained by theta {explained:.2e}")
+        assert err <= explained + 1e-5, (name, err, explained)
+        assert err <= 1e-3, (name, err)                     # and theta's 1e-4 moves no output by more than this
 
 
 def test_surface3d_with_optimizer_reaches_reference_optimum():
@@ -382,7 +401,9 @@ def test_surface3d_with_optimizer_reaches_reference_optimum():
     np.random.seed(0)
     gp = GaussianProcess(kernel=sk_kernel(0.1, [0.1], 1e-4), verbose=False)
     gp.fit(src, g["target"] - src)
-    assert gp.gp.log_marginal_likelihood_value_ >= float(g["lml_fit"]) - 1e-6 * abs(float(g["lml_fit"]))
+    lml_ref = float(g["lml_fit"])
+    print(f"surface-3D optimizer: LML {gp.gp.log_marginal_likelihood_value_!r} vs sklearn {lml_ref!r}")
+    assert gp.gp.log_marginal_likelihood_value_ >= lml_ref - 1e-8 * abs(lml_ref)
     assert_parity(np.asarray(gp.kernel.theta), g["theta_fit"], 1e-3, "fitted theta")
 
 

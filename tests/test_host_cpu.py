@@ -42,7 +42,8 @@ def test_no_cpu_fallback():
 
 def test_product_package_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "gaussian_process_transportation_amd")
-    for dirpath, _, files in os.walk(pkg):
+    for dirpath, dirs, files in os.walk(pkg):
+        dirs[:] = [d for d in dirs if d != "build"]          # untracked build scratch (objects, A/B libraries)
         for f in files:
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()

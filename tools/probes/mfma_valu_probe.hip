@@ -67,7 +67,7 @@ double run(const char* name, double* out, const double* in, int blocks, double b
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
     }
     const double ns_iter = best * 1e6 / iters;      // per loop iteration of one wave (2 waves share a SIMD)
-    const double tf = 2.0 * 2048 * NMFMA * iters * 8.0 * blocks / (best * 1e-3) / 1e12;
+    const double tf = 2048.0 * NMFMA * iters * 8.0 * blocks / (best * 1e-3) / 1e12;   // 2048 = 2 * 16 * 16 * 4 flop per MFMA
     printf("%-10s NMFMA=%2d NV=%3d  %8.1f ns/iter  %6.2f TF", name, NMFMA, NV, ns_iter, tf);
     if (base_ns > 0 && NV > 0) printf("   +%.2f ns per filler instr per wave (%.1f cyc @2.4GHz, /2 waves = %.1f)", (ns_iter - base_ns) / NV,
                                       (ns_iter - base_ns) / NV * 2.4, (ns_iter - base_ns) / NV * 2.4 / 2);
