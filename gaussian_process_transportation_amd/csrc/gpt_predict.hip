@@ -36,6 +36,7 @@ template <> struct El<double> {
     static constexpr int A_STEP = 1024, A_GROUP = 128;     // avec per k4-step of a tile / per row group inside it
     static constexpr int SUBS = 4;                         // sub-chunks of 8 k4-steps per LDS chunk: 2 x 32 steps x 2 KiB = 128 KiB
     static constexpr int PF = 2;                           // A fragments are requested this many k4-steps (of 1024 cycles) ahead
+    static constexpr bool DIAG_LDS = false;                // the B image of a diagonal tile (256 KiB) does not fit in LDS
     struct AF { d2 lo, hi; };
     static __device__ __forceinline__ void lda(AF& a, const avec* __restrict__ p, const int lane) { a.lo = p[lane]; a.hi = p[lane + 64]; }
     static __device__ __forceinline__ void keep(const AF& a, const v4& b) { asm volatile("" :: "v"(a.lo), "v"(a.hi), "v"(b)); }
@@ -62,6 +63,10 @@ template <> struct El<float> {
 #endif
     static constexpr int SUBS = GPT_F32_SUBS;              // 2 x 32 steps x 1 KiB = 64 KiB (64-step chunks measured 4 % slower: profiles/r02_svgp_variants.txt)
     static constexpr int PF = GPT_F32_PF;                  // an fp32 MFMA block lasts 512 cycles, less than an L2 round trip under load
+#ifndef GPT_F32_DIAG_LDS
+#define GPT_F32_DIAG_LDS 1
+#endif
+    static constexpr bool DIAG_LDS = GPT_F32_DIAG_LDS != 0;   // diagonal tiles of the reload sweeps: B image (128 KiB) staged in LDS
     struct AF { f4 v; };
     static __device__ __forceinline__ void lda(AF& a, const avec* __restrict__ p, const int lane) { a.v = p[lane]; }
     static __device__ __forceinline__ void keep(const AF& a, const v4& b) { asm volatile("" :: "v"(a.v), "v"(b)); }
@@ -245,7 +250,11 @@ void launch_mean_jac(hipStream_t s, const KernelParams& p, const void* Xs, const
 #define GPT_ABL 0
 #endif
 constexpr int VAR_SUB = 8;          // k4-steps per sub-chunk (= waves per workgroup: wave w fills step w of each)
-template <typename T> constexpr size_t var_lds_bytes() { return (size_t)2 * VAR_SUB * El<T>::SUBS * 64 * 4 * sizeof(T); }   // 128 KiB
+// chunk double buffer (fp64: 2 x 32 steps x 2 KiB = 128 KiB; fp32: 64 KiB) or, fp32, the B image of a diagonal tile (128 steps x 1 KiB)
+template <typename T> constexpr size_t var_lds_bytes() {
+    constexpr size_t chunks = (size_t)2 * VAR_SUB * El<T>::SUBS * 64 * 4 * sizeof(T), image = (size_t)WT_K4 * 64 * 4 * sizeof(T);
+    return (El<T>::DIAG_LDS && image > chunks) ? image : chunks;
+}
 
 template <typename T, int NCOMP, bool CROSS, int KT>
 __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, const T* __restrict__ Xs,
@@ -466,36 +475,70 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
             for (int ch = ch0; ch + 1 < ch1; ++ch) chunk(std::true_type{}, ch);
             if (ch1 > ch0) chunk(std::false_type{}, ch1 - 1);
             if (!GEN && has_diag && GPT_ABL != 3) {
-                // Diagonal tile of a reload sweep, barrier-free: every wave runs its own 16 (g + 1) k-steps with A from
-                // Wf and B straight from the scratch image (both one MFMA block ahead; program order pinned with
-                // sched_barrier so hipcc keeps the loads away from their first use).  No lock-step, so the waves with
-                // g and 7 - g that share a SIMD add up to the same work on every SIMD: the tile costs 0.56 of a full one
-                // instead of 0.75.
+                // Diagonal tile of a reload sweep, barrier-free: every wave runs its own 16 (g + 1) k-steps on its own.  No
+                // lock-step, so the waves with g and 7 - g that share a SIMD add up to the same work on every SIMD: the tile
+                // costs 0.56 of a full one instead of the 0.75 it costs inside the lock-step pipeline.
                 const int kd0 = ib * WT_K4;                              // first k-step of the diagonal tile
-                const int limit = 16 * (g + 1);                          // even
+                const int limit = 16 * (g + 1);                          // multiple of 16
                 const avec* ap = wuni + (S_ib + kd0) * A_STEP;
                 const v4* bp = buni + (size_t)kd0 * 64;
                 auto ldA = [&](AF& a, const int k) {
                     const int kk = k < limit ? k : limit - 1;            // clamped: redundant, in bounds
                     El<T>::lda(a, ap + (size_t)kk * A_STEP, lane);
                 };
-                auto ldB = [&](v4& b, const int k) {
-                    const int kk = k < limit ? k : limit - 1;
-                    b = (bp + (size_t)kk * 64)[lane];
-                };
-                AF a0, a1;
-                v4 b0, b1;
-                ldA(a0, 0); ldA(a1, 1); ldB(b0, 0);
-                for (int k4 = 0; k4 < limit; k4 += 2) {
-                    ldB(b1, k4 + 1);
-                    __builtin_amdgcn_sched_barrier(0);
-                    El<T>::mfma16(acc, a0, b0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    ldA(a0, k4 + 2); ldB(b0, k4 + 2);
-                    __builtin_amdgcn_sched_barrier(0);
-                    El<T>::mfma16(acc, a1, b1);
-                    __builtin_amdgcn_sched_barrier(0);
-                    ldA(a1, k4 + 3);
+                if constexpr (El<T>::DIAG_LDS) {
+                    // fp32: B through LDS.  With each wave re-reading its 16 (g + 1) steps of the B image from L2 / Infinity Cache
+                    // (as the fp64 path below does) the tile cost 0.75 of a full one after all: 576 KiB per tile and workgroup
+                    // in half the time an fp64 tile gives (profiles/r02_svgp_variants.txt).  The whole image of the tile — 128
+                    // k-steps x 1 KiB — fits in LDS now that the chunk buffers are free (the last chunk's barrier has passed):
+                    // the 8 waves copy it ONCE, 16 k-steps each, then run barrier-free with B from LDS.
+                    v4* const img = reinterpret_cast<v4*>(Bs_dyn);       // [k-step 0..128)[lane]
+                    constexpr int DP = El<T>::PF;
+                    AF a[DP];
+#pragma unroll
+                    for (int i = 0; i < DP; ++i) ldA(a[i], i);
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        v4 r[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) r[j] = (bp + (size_t)(w + 8 * (8 * half + j)) * 64)[lane];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) img[(w + 8 * (8 * half + j)) * 64 + lane] = r[j];
+                    }
+                    __syncthreads();
+                    v4 b_nxt = img[lane];
+                    for (int k4 = 0; k4 < limit; k4 += DP) {
+#pragma unroll
+                        for (int i = 0; i < DP; ++i) {
+                            const v4 b = b_nxt;
+                            const int kn = (k4 + i + 1 < limit) ? (k4 + i + 1) : (limit - 1);
+                            b_nxt = img[kn * 64 + lane];
+                            El<T>::mfma16(acc, a[i], b);
+                            ldA(a[i], k4 + i + DP);
+                        }
+                    }
+                    __syncthreads();                                     // the image is free again (next sweep's first fill)
+                } else {
+                    // fp64: A from Wf and B straight from the scratch image, both one MFMA block (1024 cycles) ahead; program
+                    // order pinned with sched_barrier so hipcc keeps the loads away from their first use.
+                    auto ldB = [&](v4& b, const int k) {
+                        const int kk = k < limit ? k : limit - 1;
+                        b = (bp + (size_t)kk * 64)[lane];
+                    };
+                    AF a0, a1;
+                    v4 b0, b1;
+                    ldA(a0, 0); ldA(a1, 1); ldB(b0, 0);
+                    for (int k4 = 0; k4 < limit; k4 += 2) {
+                        ldB(b1, k4 + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        El<T>::mfma16(acc, a0, b0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        ldA(a0, k4 + 2); ldB(b0, k4 + 2);
+                        __builtin_amdgcn_sched_barrier(0);
+                        El<T>::mfma16(acc, a1, b1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        ldA(a1, k4 + 3);
+                    }
                 }
             }
             if (vslot >= 0) {
