@@ -424,6 +424,7 @@ def run_svgp(args):
         value = world * M * args.steps / elapsed
         fq, fq_var = svgp_flops_per_query(Z, D, T)
         achieved = fq_var * M / (kern_ms * 1e-3) / 1e12
+        traffic, traffic_source = pmc_traffic("svgp", Z, M)
         out = {
             "metric": "SVGP-MIMO posterior (mean+std+Jacobian+Jacobian std) preds/sec, 2048 inducing pts, 3 tasks, 3-D fp32",
             "value": value, "unit": "predictions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -435,7 +436,7 @@ def run_svgp(args):
             "flops_per_query": fq, "achieved_tflops_whole_path": value * fq / 1e12 / world,
             "roofline": {"bound": "mfma", "kernel": "k_var<float> (stacked per-task triangular MFMA GEMM, v_mfma_f32_16x16x4_f32)",
                          "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "traffic_source": None,
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel_ms": kern_ms, "mean_jac_kernel_ms": mj_ms},
             "fit_ms": fit_ms, "bcast_ms": bcast_ms, "bcast_bytes": bcast_bytes, "ranks_seen": ranks_seen,
         }

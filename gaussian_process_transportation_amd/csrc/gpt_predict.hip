@@ -37,6 +37,7 @@ template <> struct El<double> {
     static constexpr int SUBS = 4;                         // sub-chunks of 8 k4-steps per LDS chunk: 2 x 32 steps x 2 KiB = 128 KiB
     static constexpr int PF = 2;                           // A fragments are requested this many k4-steps (of 1024 cycles) ahead
     static constexpr bool DIAG_LDS = false;                // the B image of a diagonal tile (256 KiB) does not fit in LDS
+    static constexpr bool BATCH_PROLOGUE = false;          // measured in round 1: no gain on the long fp64 sweeps
     struct AF { d2 lo, hi; };
     static __device__ __forceinline__ void lda(AF& a, const avec* __restrict__ p, const int lane) { a.lo = p[lane]; a.hi = p[lane + 64]; }
     static __device__ __forceinline__ void keep(const AF& a, const v4& b) { asm volatile("" :: "v"(a.lo), "v"(a.hi), "v"(b)); }
@@ -67,6 +68,10 @@ template <> struct El<float> {
 #define GPT_F32_DIAG_LDS 1
 #endif
     static constexpr bool DIAG_LDS = GPT_F32_DIAG_LDS != 0;   // diagonal tiles of the reload sweeps: B image (128 KiB) staged in LDS
+#ifndef GPT_F32_BATCH_PROLOGUE
+#define GPT_F32_BATCH_PROLOGUE 1
+#endif
+    static constexpr bool BATCH_PROLOGUE = GPT_F32_BATCH_PROLOGUE != 0;
     struct AF { f4 v; };
     static __device__ __forceinline__ void lda(AF& a, const avec* __restrict__ p, const int lane) { a.v = p[lane]; }
     static __device__ __forceinline__ void keep(const AF& a, const v4& b) { asm volatile("" :: "v"(a.v), "v"(b)); }
@@ -398,11 +403,21 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
             // LDS pipeline: see below.  A generating sweep keeps it in (its fragments are not in the scratch image yet).
             const int lock_end = ((GEN || !has_diag) ? k_hi : ib) * WT_K4;
             const int ch0 = K0 / VAR_CH, ch1 = lock_end / VAR_CH;              // lock-step chunks [ch0, ch1)
-            if (ch1 > ch0) {
+            if (ch1 > ch0) {                                  // first chunk: wave w fills steps w, w+8, w+16, w+24
+                if (!GEN && El<T>::BATCH_PROLOGUE) {
+                    // the four reloads in flight together instead of load -> wait -> write four times (short fp32 sweeps:
+                    // 12 per block at configs[4], each opening with this latency)
+                    v4 pre[VAR_SUBS];
 #pragma unroll
-                for (int j = 0; j < VAR_SUBS; ++j) {          // first chunk: wave w fills steps w, w+8, w+16, w+24
-                    fetch(K0 + j * VAR_SUB + w);
-                    produce(ch0 & 1, K0 + j * VAR_SUB + w);
+                    for (int j = 0; j < VAR_SUBS; ++j) pre[j] = (buni + (size_t)(K0 + j * VAR_SUB + w) * 64)[lane];
+#pragma unroll
+                    for (int j = 0; j < VAR_SUBS; ++j) *reinterpret_cast<v4*>(Bs(ch0 & 1, (K0 + j * VAR_SUB + w) % VAR_CH)) = pre[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < VAR_SUBS; ++j) {
+                        fetch(K0 + j * VAR_SUB + w);
+                        produce(ch0 & 1, K0 + j * VAR_SUB + w);
+                    }
                 }
             }
             constexpr int PF = El<T>::PF;                  // divides VAR_SUB, so step s of every sub-chunk uses ring slot s % PF

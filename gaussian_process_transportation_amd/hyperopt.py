@@ -6,8 +6,8 @@ theta = log(hyper-parameters), first from the kernel's own theta, then from `n_r
 starting points drawn log-uniformly inside the kernel's bounds with the GLOBAL numpy RNG
 (`random_state=None` -> `np.random.mtrand._rand`), keeping the best optimum.
 
-Here the driver is the same (scipy's L-BFGS-B on the host, same bounds, same RNG draws in the same
-order); every objective evaluation — Gram, Cholesky, alpha, K^-1 and the traces of the gradient
+Here the driver is the same (scipy's L-BFGS-B on the host — or the caller's own `optimizer(obj_func,
+initial_theta, bounds)` callable, sklearn's protocol — same bounds, same RNG draws in the same order); every objective evaluation — Gram, Cholesky, alpha, K^-1 and the traces of the gradient
 (_gpr.py:537-652) — runs on the GPU (`gpt_fit` + `gpt_lml_gradient`).  The scikit-learn kernel object is
 used only as the container of theta / bounds / fixed flags."""
 from __future__ import annotations
@@ -47,8 +47,8 @@ def optimize_hyperparameters(gp, c0, ls0, noise0):
     kernel = gp._kernel_in
     if kernel.n_dims == 0:
         return c0, ls0, noise0, None
-    if gp.optimizer != "fmin_l_bfgs_b":
-        raise ValueError(f"Unknown optimizer {gp.optimizer}.")        # sklearn/_gpr.py:668-669 (callables: not supported here)
+    if gp.optimizer != "fmin_l_bfgs_b" and not callable(gp.optimizer):
+        raise ValueError(f"Unknown optimizer {gp.optimizer}.")        # sklearn/_gpr.py:668-669
     if gp._handle is None:
         gp._handle = _lib.Handle(gp.device)
     h = gp._handle
@@ -65,7 +65,14 @@ def optimize_hyperparameters(gp, c0, ls0, noise0):
             return np.inf, np.zeros_like(theta)
         return -lml, -grad[free]
 
+    def obj_func(theta, eval_gradient=True):               # the callable-optimizer protocol of sklearn/_gpr.py:296-305
+        value, grad = objective(np.asarray(theta, dtype=np.float64))
+        return (value, grad) if eval_gradient else value
+
     def run(theta_init, bounds):
+        if callable(gp.optimizer):                          # sklearn/_gpr.py:664-667
+            theta_opt, func_min = gp.optimizer(obj_func, theta_init, bounds=bounds)
+            return np.asarray(theta_opt, dtype=np.float64), float(func_min)
         res = scipy.optimize.minimize(objective, theta_init, method="L-BFGS-B", jac=True, bounds=bounds)
         if res.status != 0:                                # sklearn's _check_optimize_result("lbfgs", ...)
             warnings.warn(f"lbfgs failed to converge (status={res.status}): {res.message}")

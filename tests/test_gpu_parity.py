@@ -364,8 +364,8 @@ def test_lml_value_and_gradient_vs_sklearn(name):
 def test_letterS_with_optimizer_matches_reference_fit():
     """Config 1 end to end with the reference's default optimizer: same L-BFGS-B driver and RNG protocol as
     sklearn, objective on the GPU.  What is asserted: (1) the optimum is as good as sklearn's (LML not lower beyond
-    1e-8 relative), (2) theta agrees to 1e-4 — the optimizer's own stopping tolerance, two runs of L-BFGS-B stop at
-    slightly different points of a flat optimum — and (3) the outputs differ from the reference's by no more than what
+    1e-8 relative), (2) theta agrees to 1e-6 — the same driver fed objective values that agree to rounding takes the same
+    steps (measured 1e-10) — and (3) the outputs differ from the reference's by no more than what
     that difference in theta explains: the same GPU path refitted at the REFERENCE's theta reproduces the golden
     outputs to 1e-5 (test_letterS_transport_fixed_theta), so |out(theta_gpu) - golden| must be within
     |out(theta_gpu) - out(theta_ref)| + 1e-5 of the array scale."""
@@ -381,7 +381,7 @@ def test_letterS_with_optimizer_matches_reference_fit():
     lml_ref = float(g["lml_fit"])
     assert gp.gp.log_marginal_likelihood_value_ >= lml_ref - 1e-8 * abs(lml_ref)
     assert gp.gp.log_marginal_likelihood_value_ == pytest.approx(lml_ref, rel=1e-6)
-    assert_parity(np.asarray(gp.kernel.theta), g["theta_fit"], 1e-4, "fitted theta")
+    assert_parity(np.asarray(gp.kernel.theta), g["theta_fit"], 1e-6, "fitted theta")      # measured: ~1e-10
     at_ref = _transport(g)                                   # same path, hyper-parameters fixed at the reference's optimum
     for name, got, fixed, ref in (("traj", tr.training_traj, at_ref.training_traj, g["traj"]), ("std", tr.std, at_ref.std, g["std"]),
                                   ("vel", tr.training_delta, at_ref.training_delta, g["vel"]),
@@ -391,7 +391,7 @@ def test_letterS_with_optimizer_matches_reference_fit():
         err = np.max(np.abs(got - ref)) / scale
         print(f"letter-S optimizer {name}: vs golden {err:.2e}, explained by theta {explained:.2e}")
         assert err <= explained + 1e-5, (name, err, explained)
-        assert err <= 1e-3, (name, err)                     # and theta's 1e-4 moves no output by more than this
+        assert err <= 1e-6, (name, err)                     # measured 4e-12 .. 2e-11 (round 1 allowed 1e-3 here)
 
 
 def test_surface3d_with_optimizer_reaches_reference_optimum():
@@ -747,9 +747,9 @@ def test_svgp_fp32_config5_shape():
     fp32 prediction (factorisation in fp64, results rounded once when the model is packed).
     PARITY UNPINNED (gpytorch absent, the reference holds no fixture): the yardstick is the fp64 CPU restatement.
     Tolerance: fp32 sums of 2048 products that cancel (alpha = K^-1 y has entries ~1/lambda_min) carry an error set by
-    sum|r alpha|, not by the result; the bound used is what the SAME algebra restated in the reference's arithmetic
-    (numpy float32, explicit fp32 inverse, :72-78) loses against fp64 on these inputs — the GPU path must be at least
-    as close (measured: about 10x closer, since its factorisation is fp64) — and 2e-4 of the array scale on top."""
+    sum|r alpha|, not by the result.  Two bounds: (1) 1e-4 of the array scale (measured 3e-6 .. 2e-5), (2) no worse than
+    the SAME algebra restated in the reference's arithmetic (numpy float32, explicit fp32 inverse, :72-78), which loses
+    1.4e-4 .. 7.4e-4 against fp64 on these inputs — the GPU path factorises in fp64 and is 15-90x closer."""
     from gaussian_process_transportation_amd import SVGPExactPredictor
     from oracle import gp_oracle as orc
     Z, Sigma, y, osc, ls, Xq = orc.svgp_synthetic_problem(2048, 3000)
@@ -765,7 +765,7 @@ def test_svgp_fp32_config5_shape():
         err_gpu = np.max(np.abs(g32.astype(np.float64) - r64)) / scale
         err_ref_arith = np.max(np.abs(r32.astype(np.float64) - r64)) / scale
         print(f"svgp fp32 {name}: GPU {err_gpu:.2e}, reference arithmetic {err_ref_arith:.2e} (relative to {scale:.3g})")
-        assert err_gpu <= err_ref_arith + 2e-4, (name, err_gpu, err_ref_arith)
+        assert err_gpu <= err_ref_arith and err_gpu <= 1e-4, (name, err_gpu, err_ref_arith)
         assert_parity(g64, r64, 1e-6, name + " (fp64 model)")     # the algebra itself, cond(K) ~ 1e6
     sv.close(); sv64.close()
 
@@ -874,3 +874,90 @@ def test_fp32_exact_gp_model():
     assert_parity(Lg, L, 1e-9, "L")
     assert_parity(ag, a, 1e-7, "alpha")
     h.close()
+    # the same through the mirrored class
+    from gaussian_process_transportation_amd import GaussianProcess
+    gp = GaussianProcess(kernel=sk_kernel(c, ls, noise), optimizer=None, verbose=False, dtype="float32")
+    gp.fit(X, Y)
+    m32, s32 = gp.predict(Xq, return_std=True)
+    assert m32.dtype == np.float32
+    assert_parity(m32, mean, 2e-4, "mean (GaussianProcess, fp32)")
+    assert_parity(s32, np.repeat((np.sqrt(var) - np.sqrt(noise))[:, None], 3, axis=1), 5e-3, "std (GaussianProcess, fp32)")
+    with pytest.raises(_lib.GptError):
+        gp.predict(Xq[:5], return_cov=True)                     # covariance / samples: fp64 models only
+
+
+def test_callable_optimizer_follows_sklearn_protocol():
+    """sklearn accepts `optimizer=callable(obj_func, initial_theta, bounds) -> (theta_opt, func_min)` (_gpr.py:296-305,
+    664-667).  A callable that runs scipy's L-BFGS-B itself must land where the built-in string option lands, and
+    obj_func must honour eval_gradient."""
+    import scipy.optimize
+    from gaussian_process_transportation_amd import GaussianProcess
+    g = load_golden("synthetic_3d_N256")
+    calls = {"n": 0, "value_only": None}
+
+    def my_optimizer(obj_func, initial_theta, bounds):
+        calls["n"] += 1
+        calls["value_only"] = obj_func(initial_theta, eval_gradient=False)
+        v, gr = obj_func(initial_theta)
+        assert np.isscalar(calls["value_only"]) and calls["value_only"] == v and gr.shape == initial_theta.shape
+        res = scipy.optimize.minimize(obj_func, initial_theta, method="L-BFGS-B", jac=True, bounds=bounds)
+        return res.x, res.fun
+
+    np.random.seed(3)
+    a = GaussianProcess(kernel=sk_kernel(0.1, [0.1, 0.1, 0.1], 1e-4), optimizer=my_optimizer, n_restarts_optimizer=1, verbose=False)
+    a.fit(g["X"], g["Y"])
+    np.random.seed(3)
+    b = GaussianProcess(kernel=sk_kernel(0.1, [0.1, 0.1, 0.1], 1e-4), optimizer="fmin_l_bfgs_b", n_restarts_optimizer=1, verbose=False)
+    b.fit(g["X"], g["Y"])
+    assert calls["n"] == 2                                    # the kernel's theta + one restart
+    assert_parity(np.asarray(a.kernel.theta), np.asarray(b.kernel.theta), 1e-10, "theta")
+    with pytest.raises(ValueError):
+        GaussianProcess(kernel=sk_kernel(0.1, [0.1], 1e-4), optimizer="nelder", verbose=False).fit(g["X"], g["Y"])
+
+
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-7), ("float32", 5e-4)])
+def test_svgp_transport_attribute_protocol(dtype, tol):
+    """SVGPTransport (reference: transportation/torch/stocastic_variational_gaussian_process_transportation.py:46-102) over
+    the GPU exact-conversion predictor, against the same algebra written out with the CPU oracle: affine pre-alignment,
+    mean / std of the residual field at the rotated demo, velocities through (I + J) after the affine derivative,
+    their variance from the Jacobian std, orientations through the two rotations.  PARITY UNPINNED (gpytorch and the
+    reference's `quaternion` package are absent): the oracle is this repo's restatement."""
+    from gaussian_process_transportation_amd import AffineTransform, SVGPTransport
+    from gaussian_process_transportation_amd.quaternion import quaternion_from_nonorthogonal, quaternion_multiply
+    from oracle import gp_oracle as orc
+    rng = np.random.default_rng(4)
+    N, Z, M, T, D = 400, 96, 300, 3, 3
+    src = rng.uniform(0, 1, (N, D))
+    R = np.linalg.qr(rng.standard_normal((D, D)))[0]
+    R *= np.sign(np.linalg.det(R))
+    tgt = src @ R.T + 0.3 + 0.05 * np.sin(3 * src)
+    demo = rng.uniform(0.1, 0.9, (M, D))
+    vel = rng.standard_normal((M, D)) * 0.1
+    ori = rng.standard_normal((M, 4)); ori /= np.linalg.norm(ori, axis=1, keepdims=True)
+    aff = AffineTransform(verbose=False).fit(src, tgt)
+    src_al = aff.predict(src)
+    idx = rng.choice(N, Z, replace=False)
+    A = rng.standard_normal((T, Z, Z))
+    pp = dict(x_inducing=src_al[idx], var_inducing=A @ A.transpose(0, 2, 1) / Z * 1e-3 + 1e-4 * np.eye(Z),
+              y_inducing=(tgt - src_al)[idx].T.copy(), outputscale=np.array([0.02, 0.03, 0.025]), lengthscale=np.array([0.3, 0.35, 0.25]))
+    tr = SVGPTransport(dtype=dtype, verbose=False)
+    tr.source_distribution, tr.target_distribution = src, tgt
+    tr.training_traj, tr.training_delta, tr.training_ori = demo, vel, ori
+    with pytest.raises(NotImplementedError):
+        tr.fit_transportation()                                 # variational training is gpytorch's: not rebuilt
+    tr.fit_transportation(pseudo_points=pp)
+    tr.apply_transportation()
+    # the same with the oracle
+    rot = aff.predict(demo)
+    mean, std, J, Jstd = orc.svgp_exact_oracle(rot, pp["x_inducing"], pp["var_inducing"], pp["y_inducing"], pp["outputscale"], pp["lengthscale"])
+    dA = aff.derivative(rot)
+    v1 = dA @ vel[:, :, None]
+    assert tr.training_traj_old is demo
+    assert_parity(tr.training_traj, rot + mean, tol, "training_traj")
+    assert_parity(tr.std, std, 50 * tol, "std")                 # sqrt of a variance that nearly cancels at the pseudo-points
+    assert_parity(tr.training_delta, ((np.eye(D) + J) @ v1)[:, :, 0], tol, "training_delta")
+    assert_parity(tr.var_vel_transported, (Jstd ** 2 @ v1 ** 2)[:, :, 0], 50 * tol, "var_vel_transported")
+    q = quaternion_multiply(quaternion_from_nonorthogonal(np.eye(D) + J),
+                            quaternion_multiply(quaternion_from_nonorthogonal(aff.rotation_matrix), ori))
+    assert_parity(tr.training_ori, q, 10 * tol, "training_ori")
+    assert np.allclose(np.linalg.norm(tr.training_ori, axis=1), 1.0, atol=1e-6)
