@@ -172,6 +172,7 @@ struct gpt_handle {
     // per-kernel timing of the last predict (gpt_set_profiling)
     bool profiling = false, pred_mj = false, pred_var = false;
     VarWorkspace vws;              // scratch + cached plan of the variance kernel
+    FitAux fit_aux;                // CU-masked streams + events of the overlapped factor / inverse pipeline
     double* lml_partial = nullptr; // partial sums of the LML gradient (grow-only)
     size_t lml_partial_cap = 0;
     unsigned char* cov_buf = nullptr;   // scratch of gpt_predict_cov (grow-only)
@@ -232,7 +233,7 @@ int ensure_workspace(gpt_handle* h, int64_t NP, int npass) {
     HIPCHK(hipMalloc(&h->dscal, 8 * sizeof(double)));
     HIPCHK(hipMalloc(&h->dinfo, sizeof(int)));
     {
-        const size_t a = (size_t)NP * NP / 4, b = (size_t)(NP / 512) * NP * 4;
+        const size_t a = factor_scratch_doubles((int)NP), b = (size_t)(NP / 512) * NP * 4;
         HIPCHK(hipMalloc(&h->dScr, (a > b ? a : b) * sizeof(double)));
     }
     h->ws_np = NP; h->ws_npass = npass;
@@ -327,9 +328,7 @@ int factorise(gpt_handle* h, int64_t N, int NP, int kernel_type, double c, doubl
         HIPCHK(hipMemsetAsync(h->dW, 0, (size_t)NP * NP * sizeof(double), s));
     }
     HIPCHK(hipEventRecord(h->ev[1], s));
-    launch_potrf(s, h->dK, h->dW, NP, h->dinfo);
-    HIPCHK(hipEventRecord(h->ev[2], s));
-    launch_trinv(s, h->dK, h->dW, NP, h->dScr);
+    launch_factor_inverse(s, h->dK, h->dW, NP, h->dinfo, h->dScr, &h->fit_aux, h->ev[2]);
     HIPCHK(hipEventRecord(h->ev[3], s));
     return GPT_OK;
 }
@@ -377,6 +376,7 @@ void gpt_destroy(gpt_handle* h) {
     free_staging(h);
     free_workspace(h);
     var_release(h->vws);
+    fit_aux_release(h->fit_aux);
     if (h->blob) (void)hipFree(h->blob);
     if (h->lml_partial) (void)hipFree(h->lml_partial);
     if (h->cov_buf) (void)hipFree(h->cov_buf);
@@ -455,6 +455,7 @@ static int fit_impl(gpt_handle* h, const double* X, const double* Y, int64_t N, 
     h->committed = false;
     h->have_L = h->have_W = false;
     const Layout l = make_layout(N, D, O, 1, h->dtype_next);
+    predict_warmup(l.dtype);
     if (int rc = ensure_blob(h, l)) return rc;
     if (int rc = ensure_workspace(h, l.NP, l.npass)) return rc;
     const int NP = (int)l.NP;
@@ -512,6 +513,7 @@ int gpt_fit_svgp(gpt_handle* h, const double* Z, const double* y, const double* 
     h->committed = false;
     h->have_L = h->have_W = false;
     const Layout l = make_layout(N, D, T, T, dtype);
+    predict_warmup(l.dtype);
     if (int rc = ensure_blob(h, l)) return rc;
     if (int rc = ensure_workspace(h, l.NP, l.npass)) return rc;
     const int NP = (int)l.NP;

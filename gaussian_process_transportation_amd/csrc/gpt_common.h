@@ -63,8 +63,19 @@ struct KernelParams {
 // fit
 void launch_gram(hipStream_t s, const double* Xs, int N, int NP, int ktype, double c, double diag_add, double* K);
 void launch_add_lower(hipStream_t s, double* K, const double* S, int N, int NP);
-void launch_potrf(hipStream_t s, double* K, double* W, int NP, int* info);
-void launch_trinv(hipStream_t s, const double* L, double* W, int NP, double* scratch /* >= NP*NP/4 doubles */);
+// Streams and events of the overlapped factor + inverse pipeline, owned by a handle: two streams confined to disjoint
+// halves of the CUs (hipExtStreamCreateWithCUMask).  Created on first use; `ok` false = unavailable, everything runs in
+// the caller's stream.
+struct FitAux {
+    bool tried = false, ok = false;
+    hipStream_t sa = nullptr, sb = nullptr;
+    hipEvent_t e_fork = nullptr, e_a = nullptr, e_b = nullptr;
+};
+void fit_aux_release(FitAux& aux);
+size_t factor_scratch_doubles(int NP);
+// L = chol(K) in place (lower), W = L^-1; scratch >= factor_scratch_doubles(NP); ev_factored (may be null) is recorded
+// in `s` when L is complete
+void launch_factor_inverse(hipStream_t s, double* K, double* W, int NP, int* info, double* scratch, FitAux* aux, hipEvent_t ev_factored);
 void launch_alpha(hipStream_t s, const double* W, const double* Y4, int N, int NP, double* tmp4, double* A4,
                   double* scratch /* >= (NP/512)*NP*4 doubles */);
 // W (row-major fp64, lower) * scale -> tile set `task` of the fragment-ordered stream Wf (element type dtype)
@@ -97,6 +108,7 @@ hipError_t var_prepare(VarWorkspace& ws, hipStream_t s, const KernelParams& p, i
 void launch_var(hipStream_t s, const KernelParams& p, const VarWorkspace& ws, const void* Xs, const void* Wf,
                 const void* Xq, int64_t M, int ncomp, void* var, void* Jvar, void* dvar, const double* hdr);
 void var_release(VarWorkspace& ws);
+void predict_warmup(int dtype);          // first-use setup of the prediction kernels for this element type and device
 int var_workgroups();
 
 size_t wf_elems(int NP);          // elements of ONE task's tile set (+ prefetch overrun after the last task: wf_overrun_elems)

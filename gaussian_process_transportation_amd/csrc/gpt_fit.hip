@@ -8,8 +8,10 @@
 // kept as its triangular factor W = L^-1 so that k^T K^-1 k = |W k|^2).
 #include "gpt_common.h"
 #include "gpt_exp.h"
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
+#include <vector>
 
 namespace gpt {
 
@@ -394,13 +396,13 @@ __global__ __launch_bounds__(256) void k_potrf_step(double* __restrict__ K, doub
 
 // After the last step: for every diagonal block, move the parked L11 from W into K (zeros above the diagonal)
 // and leave inv(L11) in W (the seed of launch_trinv).  One workgroup per block, all blocks in one launch.
-__global__ __launch_bounds__(256) void k_potrf_finish(double* __restrict__ K, double* __restrict__ W, int NP) {
+__global__ __launch_bounds__(256) void k_potrf_finish(double* __restrict__ K, double* __restrict__ W, int NP, int b0) {
     __shared__ double dinv[NB];
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* Ls = smem;                      // L11, row-major [NB][DS]
     double* Xs = smem + NB * DS;            // L11^-1
     const int t = threadIdx.x;
-    const size_t k0 = (size_t)blockIdx.x * NB;
+    const size_t k0 = (size_t)(b0 + blockIdx.x) * NB;
     for (int e = t; e < NB * NB; e += 256) {
         const int r = e / NB, c = e % NB;
         const double v = (c <= r) ? W[(k0 + r) * NP + k0 + c] : 0.0;
@@ -685,7 +687,15 @@ static int potrf_outer_blocks() {
     return ob;
 }
 
-void launch_potrf(hipStream_t s, double* K, double* W, int NP, int* info) {
+// Blocked Cholesky over the block columns [blk_begin, blk_end) (group-aligned), each group's trailing update over the
+// whole matrix behind it; all launches in `s`.
+static int potrf_group(int NP) {
+    int grp_env = 0;
+    if (const char* e = getenv("GPT_POTRF_GROUP")) { const int v = atoi(e); if (v >= 1 && v <= 8) grp_env = v; }
+    return grp_env ? grp_env : (NP >= 4096 ? 2 : 1);
+}
+
+static void potrf_groups(hipStream_t s, double* K, double* W, int NP, int* info, int blk_begin, int blk_end) {
     const int nb = NP / NB;
     const int ob = potrf_outer_blocks();
     constexpr size_t step_lds = (size_t)(2 * NB * PS) * sizeof(double);
@@ -701,9 +711,7 @@ void launch_potrf(hipStream_t s, double* K, double* W, int NP, int* info) {
     // (42 TFLOP/s against 50-55 at rank 256-512), happens grp times less often.
     // (measured: groups of 2 take 3 % off the Cholesky at N = 8192 and add 3-5 % at N <= 2500, where the extra thin GEMM
     // on the chain costs more than the trailing matrix's traffic; tools/gpu_fit_ab.sh with GPT_POTRF_GROUP)
-    static int grp_env = -1;
-    if (grp_env < 0) { grp_env = 0; if (const char* e = getenv("GPT_POTRF_GROUP")) { const int v = atoi(e); if (v >= 1 && v <= 8) grp_env = v; } }
-    const int grp = grp_env ? grp_env : (NP >= 4096 ? 2 : 1);
+    const int grp = potrf_group(NP);
     auto syrk = [&](int row0, int ncols, int kcol0, int kw) {      // A[row0.., row0..row0+ncols) -= P P^T, P = A[row0.., kcol0..kcol0+kw)
         const int rem = NP - row0;
         if (rem <= 0 || kw <= 0) return;
@@ -716,7 +724,7 @@ void launch_potrf(hipStream_t s, double* K, double* W, int NP, int* info) {
         launch_gemm<true>(s, c);
     };
     const int gw = grp * ob;                                        // blocks per group
-    for (int g0 = 0; g0 < nb; g0 += gw) {
+    for (int g0 = blk_begin; g0 < blk_end; g0 += gw) {
         const int gend = g0 + gw < nb ? g0 + gw : nb;
         for (int p0 = g0; p0 < gend; p0 += ob) {
             const int pend = p0 + ob < gend ? p0 + ob : gend;
@@ -726,7 +734,12 @@ void launch_potrf(hipStream_t s, double* K, double* W, int NP, int* info) {
         }
         syrk(gend * NB, NP - gend * NB, g0 * NB, (gend - g0) * NB);                  // everything behind the group
     }
-    hipLaunchKernelGGL(k_potrf_finish, dim3(nb), dim3(256), fin_lds, s, K, W, NP);
+}
+
+// diagonal blocks [b0, b1): parked L_kk from W into K, inv(L_kk) into W (the seeds of the triangular inverse)
+static void potrf_finish(hipStream_t s, double* K, double* W, int NP, int b0, int b1) {
+    constexpr size_t fin_lds = (size_t)(2 * NB * DS) * sizeof(double);
+    if (b1 > b0) hipLaunchKernelGGL(k_potrf_finish, dim3(b1 - b0), dim3(256), fin_lds, s, K, W, NP, b0);
 }
 
 // =====================================================================================
@@ -734,31 +747,130 @@ void launch_potrf(hipStream_t s, double* K, double* W, int NP, int* info) {
 // Level s (s = NB, 2NB, ...): for each pair of adjacent s-blocks
 //     T   = L21 * W11          (W11 lower triangular: k >= j0)
 //     W21 = -W22 * T           (W22 lower triangular: k <  i0 + 128)
-// T lives in `scratch` (>= NP*NP/4 doubles; the not-yet-written Wf buffer is used).
+// T lives in `scratch` (>= n*n/4 doubles).  Inverts the diagonal sub-block [off, off + n) of a matrix with leading dimension NP.
 // =====================================================================================
-void launch_trinv(hipStream_t s, const double* L, double* W, int NP, double* scratch) {
-    for (long sz = NB; sz < NP; sz *= 2) {
-        const int npairs = (int)((NP + 2 * sz - 1) / (2 * sz));
+static void trinv_levels(hipStream_t s, const double* L, double* W, int NP, int off, int n, double* scratch) {
+    L += (size_t)off * NP + off;
+    W += (size_t)off * NP + off;
+    for (long sz = NB; sz < n; sz *= 2) {
+        const int npairs = (int)((n + 2 * sz - 1) / (2 * sz));
         // last pair: rows available for the second block
         const long r0_last = (long)(npairs - 1) * 2 * sz;
-        long m_last = NP - r0_last - sz;
-        int nb = npairs;
-        if (m_last <= 0) { nb = npairs - 1; m_last = sz; }
-        if (nb <= 0) continue;
+        long m_last = n - r0_last - sz;
+        int nbp = npairs;
+        if (m_last <= 0) { nbp = npairs - 1; m_last = sz; }
+        if (nbp <= 0) continue;
         if (m_last > sz) m_last = sz;
         const long pair_stride = 2 * sz * (long)NP + 2 * sz;
         GemmArgs a{};
         a.A = L + sz * (long)NP; a.lda = NP; a.sA = pair_stride;            // L21
         a.B = W; a.ldb = NP; a.sB = pair_stride;                            // W11
         a.C = scratch; a.ldc = sz; a.sC = sz * sz;                          // T
-        a.M = (int)sz; a.M_last = (int)m_last; a.N = (int)sz; a.K = a.K_last = (int)sz; a.nbatch = nb;
+        a.M = (int)sz; a.M_last = (int)m_last; a.N = (int)sz; a.K = a.K_last = (int)sz; a.nbatch = nbp;
         a.alpha = 1.0; a.beta = 0.0; a.b_lower = 1;
         launch_gemm<false>(s, a);
         GemmArgs c{};
         c.A = W + sz * (long)NP + sz; c.lda = NP; c.sA = pair_stride;       // W22
         c.B = scratch; c.ldb = sz; c.sB = sz * sz;                          // T
         c.C = W + sz * (long)NP; c.ldc = NP; c.sC = pair_stride;            // W21
-        c.M = (int)sz; c.M_last = (int)m_last; c.N = (int)sz; c.K = (int)sz; c.K_last = (int)m_last; c.nbatch = nb;
+        c.M = (int)sz; c.M_last = (int)m_last; c.N = (int)sz; c.K = (int)sz; c.K_last = (int)m_last; c.nbatch = nbp;
+        c.alpha = -1.0; c.beta = 0.0; c.a_lower = 1;
+        launch_gemm<false>(s, c);
+    }
+}
+
+void fit_aux_release(FitAux& aux) {
+    for (hipEvent_t* e : {&aux.e_fork, &aux.e_a, &aux.e_b}) { if (*e) (void)hipEventDestroy(*e); *e = nullptr; }
+    if (aux.sa) (void)hipStreamDestroy(aux.sa);
+    if (aux.sb) (void)hipStreamDestroy(aux.sb);
+    aux.sa = aux.sb = nullptr;
+    aux.tried = aux.ok = false;
+}
+
+// Two CU-masked streams (hipExtStreamCreateWithCUMask): bits [0, split) and the rest — bit i of the mask is CU i in the
+// driver's numbering, dealt round-robin over the XCDs, so both halves span all 8 XCDs.  tools/probes/cumask_probe.hip: a
+// launch chain on one mask and a bulk kernel on the other run side by side without delaying each other, which two plain
+// streams do not (a short kernel queues behind the bulk kernel's grid).
+static bool fit_aux_init(FitAux& aux) {
+    if (aux.tried) return aux.ok;
+    aux.tried = true;
+    if (const char* env = getenv("GPT_FIT_OVERLAP")) { if (atoi(env) == 0) return false; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, current_device()) != hipSuccess) return false;
+    const int ncu = prop.multiProcessorCount;
+    int split = ncu / 2;
+    if (const char* e = getenv("GPT_FIT_CHAIN_CUS")) split = atoi(e);
+    if (split < 16 || split > ncu - 16) return false;
+    const int words = (ncu + 31) / 32;
+    std::vector<uint32_t> ma(words, 0), mb(words, 0);
+    for (int i = 0; i < ncu; ++i) (i < split ? ma : mb)[i / 32] |= 1u << (i % 32);
+    if (hipExtStreamCreateWithCUMask(&aux.sa, words, ma.data()) != hipSuccess) { aux.sa = nullptr; (void)hipGetLastError(); return false; }
+    if (hipExtStreamCreateWithCUMask(&aux.sb, words, mb.data()) != hipSuccess) {
+        (void)hipStreamDestroy(aux.sa); aux.sa = aux.sb = nullptr; (void)hipGetLastError();
+        return false;
+    }
+    bool ok = true;
+    for (hipEvent_t* e : {&aux.e_fork, &aux.e_a, &aux.e_b}) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
+    aux.ok = ok;
+    return ok;
+}
+
+size_t factor_scratch_doubles(int NP) { return (size_t)NP * NP / 4 + (size_t)NP * NP / 16 + 4096; }
+
+// L = chol(K) in place and W = L^-1.  `ev_factored` (may be null) is recorded in `s` once L is complete.
+//
+// Serial form (NP < 4096, or no masked streams): Cholesky, finish, recursive-doubling inverse, one after the other in `s`.
+// Overlapped form: the second half of the Cholesky is bound by its launch chain (64 steps + thin updates: most CUs idle),
+// while the inverse of the first half and T21 = L21 W11 — 5/8 of the inverse's flops — need nothing but the first half's
+// columns, final by then.  So after the first half: the rest of the Cholesky runs on one half of the CUs, W11 and T21 on the
+// other; afterwards W22 and W21 = -W22 T21 on the whole chip.
+void launch_factor_inverse(hipStream_t s, double* K, double* W, int NP, int* info, double* scratch, FitAux* aux, hipEvent_t ev_factored) {
+    const int nb = NP / NB;
+    const int gw = potrf_group(NP) * potrf_outer_blocks();
+    int hb = nb / 2 / gw * gw;                                      // split block column, group-aligned
+    const bool overlap = NP >= 4096 && hb >= gw && aux && fit_aux_init(*aux);
+    if (!overlap) {
+        potrf_groups(s, K, W, NP, info, 0, nb);
+        potrf_finish(s, K, W, NP, 0, nb);
+        if (ev_factored) hipEventRecord(ev_factored, s);
+        trinv_levels(s, K, W, NP, 0, NP, scratch);
+        return;
+    }
+    const int h = hb * NB, r = NP - h;
+    double* T21 = scratch;                                          // r x h, row-major
+    double* inner = scratch + (size_t)NP * NP / 4;                  // scratch of the half-size inverses
+    potrf_groups(s, K, W, NP, info, 0, hb);                         // columns [0, h) final, A22 carries their update
+    hipEventRecord(aux->e_fork, s);
+    hipStreamWaitEvent(aux->sa, aux->e_fork, 0);
+    hipStreamWaitEvent(aux->sb, aux->e_fork, 0);
+    // stream a: the rest of the factorisation
+    potrf_groups(aux->sa, K, W, NP, info, hb, nb);
+    potrf_finish(aux->sa, K, W, NP, hb, nb);
+    hipEventRecord(aux->e_a, aux->sa);
+    // stream b: W11 = L11^-1, T21 = L21 W11
+    potrf_finish(aux->sb, K, W, NP, 0, hb);
+    trinv_levels(aux->sb, K, W, NP, 0, h, inner);
+    {
+        GemmArgs a{};
+        a.A = K + (size_t)h * NP; a.lda = NP;                       // L21 (r x h)
+        a.B = W; a.ldb = NP;                                        // W11 (h x h, lower)
+        a.C = T21; a.ldc = h;
+        a.M = a.M_last = r; a.N = h; a.K = a.K_last = h; a.nbatch = 1;
+        a.alpha = 1.0; a.beta = 0.0; a.b_lower = 1;
+        launch_gemm<false>(aux->sb, a);
+    }
+    hipEventRecord(aux->e_b, aux->sb);
+    hipStreamWaitEvent(s, aux->e_a, 0);
+    if (ev_factored) hipEventRecord(ev_factored, s);
+    hipStreamWaitEvent(s, aux->e_b, 0);
+    // whole chip again: W22 = L22^-1, W21 = -W22 T21
+    trinv_levels(s, K, W, NP, h, r, inner);
+    {
+        GemmArgs c{};
+        c.A = W + (size_t)h * NP + h; c.lda = NP;                   // W22 (r x r, lower)
+        c.B = T21; c.ldb = h;
+        c.C = W + (size_t)h * NP; c.ldc = NP;                       // W21
+        c.M = c.M_last = r; c.N = h; c.K = c.K_last = r; c.nbatch = 1;
         c.alpha = -1.0; c.beta = 0.0; c.a_lower = 1;
         launch_gemm<false>(s, c);
     }

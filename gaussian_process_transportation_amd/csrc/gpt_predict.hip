@@ -535,7 +535,9 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
                     __syncthreads();                                     // the image is free again (next sweep's first fill)
                 } else {
                     // fp64: A from Wf and B straight from the scratch image, both one MFMA block (1024 cycles) ahead; program
-                    // order pinned with sched_barrier so hipcc keeps the loads away from their first use.
+                    // order pinned with sched_barrier so hipcc keeps the loads away from their first use.  (Staging the first
+                    // 64 k-steps of the image in LDS, as far as 128 KiB go, was 1.1 % slower — two more barriers per tile — for 4 %
+                    // fewer fetched bytes: profiles/r02_kvar_diag_image_fp64.txt.)
                     auto ldB = [&](v4& b, const int k) {
                         const int kk = k < limit ? k : limit - 1;
                         b = (bp + (size_t)kk * 64)[lane];
@@ -704,19 +706,30 @@ __global__ __launch_bounds__(64) void k_var_finalize(KernelParams p, VarPlanDev 
     }
 }
 
+// Dynamic LDS beyond the default limit is an opt-in per kernel and device.  Also what loads this translation unit's code
+// object: called from the fit (predict_warmup), so that the first predict of a process does not pay for it (13 ms once,
+// profiles/r02_first_call_latency.log).
+template <typename T>
+static void var_kernel_setup() {
+    static PerDeviceOnce once;
+    if (!once.first()) return;
+    const void* fns[] = {reinterpret_cast<const void*>(k_var<T, 1, false, KT_RBF>), reinterpret_cast<const void*>(k_var<T, 4, true, KT_RBF>),
+                         reinterpret_cast<const void*>(k_var<T, 4, false, KT_RBF>), reinterpret_cast<const void*>(k_var<T, 3, false, KT_RBF>),
+                         reinterpret_cast<const void*>(k_var<T, 1, false, KT_MATERN12>),
+                         reinterpret_cast<const void*>(k_var<T, 1, false, KT_MATERN32>), reinterpret_cast<const void*>(k_var<T, 1, false, KT_MATERN52>)};
+    for (const void* f : fns) hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)var_lds_bytes<T>());
+}
+
+void predict_warmup(int dtype) {
+    if (dtype == DT_F32) var_kernel_setup<float>(); else var_kernel_setup<double>();
+}
+
 template <typename T>
 static void launch_var_t(hipStream_t s, const KernelParams& p, const VarWorkspace& ws, const T* Xs, const T* Wf,
                          const T* Xq, int64_t M, int ncomp, T* var, T* Jvar, T* dvar, const double* hdr) {
     const VarPlanDev& pl = ws.plan->d;
     constexpr size_t lds = var_lds_bytes<T>();
-    static PerDeviceOnce once;
-    if (once.first()) {      // dynamic LDS beyond the default limit is an opt-in per kernel and device
-        const void* fns[] = {reinterpret_cast<const void*>(k_var<T, 1, false, KT_RBF>), reinterpret_cast<const void*>(k_var<T, 4, true, KT_RBF>),
-                             reinterpret_cast<const void*>(k_var<T, 4, false, KT_RBF>), reinterpret_cast<const void*>(k_var<T, 3, false, KT_RBF>),
-                             reinterpret_cast<const void*>(k_var<T, 1, false, KT_MATERN12>),
-                             reinterpret_cast<const void*>(k_var<T, 1, false, KT_MATERN32>), reinterpret_cast<const void*>(k_var<T, 1, false, KT_MATERN52>)};
-        for (const void* f : fns) hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    }
+    var_kernel_setup<T>();
     T* slab = static_cast<T*>(ws.slab);
     T* vslab = static_cast<T*>(ws.vslab);
     T* bscr = static_cast<T*>(ws.bscratch);

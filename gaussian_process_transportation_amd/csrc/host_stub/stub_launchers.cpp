@@ -15,6 +15,7 @@ static void touch_r(const void* p, size_t bytes) {
     acc = acc + b[0]; acc = acc + b[bytes - 1]; acc = acc + b[bytes / 2];
 }
 
+void predict_warmup(int) {}
 size_t wf_elems(int NP) { const size_t nb = NP / WT; return nb * (nb + 1) / 2 * WT_TILE_DOUBLES; }
 size_t wf_overrun_elems() { return WT_STEP_DOUBLES; }
 
@@ -22,9 +23,10 @@ void launch_gram(hipStream_t, const double* Xs, int, int NP, int, double, double
     touch_r(Xs, (size_t)NP * 4 * 8); touch_w(K, (size_t)NP * NP * 8);
 }
 void launch_add_lower(hipStream_t, double* K, const double* S, int N, int NP) { touch_r(S, (size_t)N * N * 8); touch_w(K, (size_t)NP * NP * 8); }
-void launch_potrf(hipStream_t, double* K, double* W, int NP, int* info) { touch_w(K, (size_t)NP * NP * 8); touch_w(W, (size_t)NP * NP * 8); *info = 0; }
-void launch_trinv(hipStream_t, const double* L, double* W, int NP, double* scratch) {
-    touch_r(L, (size_t)NP * NP * 8); touch_w(W, (size_t)NP * NP * 8); touch_w(scratch, (size_t)NP * NP / 4 * 8);
+void fit_aux_release(FitAux&) {}
+size_t factor_scratch_doubles(int NP) { return (size_t)NP * NP / 4 + (size_t)NP * NP / 16 + 4096; }
+void launch_factor_inverse(hipStream_t, double* K, double* W, int NP, int* info, double* scratch, FitAux*, hipEvent_t) {
+    touch_w(K, (size_t)NP * NP * 8); touch_w(W, (size_t)NP * NP * 8); touch_w(scratch, factor_scratch_doubles(NP) * 8); *info = 0;
 }
 void launch_alpha(hipStream_t, const double* W, const double* Y4, int, int NP, double* tmp4, double* A4, double* scratch) {
     touch_r(W, (size_t)NP * NP * 8); touch_r(Y4, (size_t)NP * 32); touch_w(tmp4, (size_t)NP * 32); touch_w(A4, (size_t)NP * 32);

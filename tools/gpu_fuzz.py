@@ -26,7 +26,7 @@ bad = 0
 h = _lib.Handle(0)
 for it in range(cases):
     N = int(rng.choice([1, 2, 5, 17, 63, 64, 65, 130, 257, 511, 513, 777, 1025, 1500, 2100, 3000]))
-    M = int(rng.choice([1, 7, 64, 65, 300, 1000, 4097]))
+    M = int(rng.choice([1, 7, 64, 65, 300, 1000, 4097, 17000, 40000]))      # cut sweeps only / whole rounds + tail
     D = int(rng.integers(1, 4))
     O = int(rng.integers(1, 7))
     kind = str(rng.choice(["rbf", "rbf", "rbf", "matern12", "matern32", "matern52"]))
@@ -57,6 +57,13 @@ for it in range(cases):
     errs["alpha"] = rel(a, o.alpha_) / max(1.0, np.linalg.cond(o.L_) ** 2 * 1e-10)   # alpha is as ill-conditioned as K
     want_der = kind == "rbf"
     out = h.predict_all(Xq, mean=True, var=True, J=want_der, Jvar=want_der, dvar=want_der)
+    alone_all = h.predict_all(Xq, J=True, Jvar=True)["Jvar"] if want_der else None
+    if M > 1500:            # the GPU predicts the whole batch; the (slow) CPU oracle checks a random subset of it
+        sub = np.sort(rng.choice(M, 1500, replace=False))
+        Xq = Xq[sub]
+        out = {k: (v[:, sub] if k == "dvar" else v[sub]) for k, v in out.items() if v is not None}
+        alone_all = alone_all[sub] if alone_all is not None else None
+        M = 1500
     mean, std = o.predict(Xq, return_std=True)
     std = std if std.ndim == 1 else std[:, 0]
     var = (std + np.sqrt(noise)) ** 2
@@ -69,14 +76,59 @@ for it in range(cases):
         errs["Jvar"] = float(np.max(np.abs(out["Jvar"] - Jv[:, 0, :])) / scale)
         errs["dvar"] = float(np.max(np.abs(out["dvar"] - o.derivative_of_variance(Xq))) / (scale ** 0.5 * (c + noise) ** 0.5 * 2))
     if want_der:                      # Jacobian variance alone: the D-columns-per-query kernel
-        alone = h.predict_all(Xq, J=True, Jvar=True)["Jvar"]
-        errs["Jvar_alone"] = float(np.max(np.abs(alone - Jv[:, 0, :])) / scale)
+        errs["Jvar_alone"] = float(np.max(np.abs(alone_all - Jv[:, 0, :])) / scale)
     for k, v in errs.items():
         worst[k] = max(worst.get(k, 0.0), v)
-    if (it + 1) % 10 == 0:
-        print(f"... {it + 1} cases", flush=True)
+    print(f"... case {it} done ({tag[:60]})", flush=True)
     if max(errs.values()) > 1e-6 or not all(np.isfinite(list(errs.values()))):
         bad += 1
         print("LARGE:", tag, {k: f"{v:.2e}" for k, v in errs.items()}, f"cond(K)~{np.linalg.cond(o.L_) ** 2:.2e}", flush=True)
 h.close()
 print(f"{cases} cases, {bad} flagged; worst errors:", {k: f"{v:.2e}" for k, v in worst.items()})
+
+# ---- multi-task (SVGP exact conversion) models, fp64 and fp32, against the CPU restatement; fp32 exact GP against the fp64 one
+worst2, bad2 = {}, 0
+for it in range(max(cases // 2, 6)):
+    Z = int(rng.choice([3, 64, 130, 511, 513, 900, 1500, 2048]))
+    T = int(rng.integers(1, 6))
+    D = int(rng.integers(1, 4))
+    M = int(rng.choice([1, 65, 460, 3000, 20000]))
+    dtype = int(rng.integers(0, 2))
+    Zp = rng.uniform(0, 1, (Z, D))
+    A = rng.standard_normal((T, Z, Z))
+    Sigma = A @ A.transpose(0, 2, 1) / Z * float(np.exp(rng.uniform(np.log(1e-3), 0))) + 1e-3 * np.eye(Z)
+    y = rng.standard_normal((T, Z))
+    osc = np.exp(rng.uniform(np.log(0.1), np.log(5.0), T))
+    ls = np.exp(rng.uniform(np.log(0.08), np.log(1.0), D))
+    Xq = rng.uniform(-0.1, 1.1, (M, D))
+    tag = f"svgp case {it}: Z={Z} T={T} D={D} M={M} {'fp32' if dtype else 'fp64'}"
+    hs = _lib.Handle(0)
+    hs.fit_svgp(Zp, y, Sigma, ls, osc, dtype=dtype)
+    out = hs.predict_all(Xq, mean=True, var=True, J=True, Jvar=True)
+    hs.close()
+    if M > 1500:
+        sub = np.sort(rng.choice(M, 1500, replace=False))
+        Xq = Xq[sub]
+        out = {k: v[sub] for k, v in out.items() if v is not None}
+    print(f"... {tag}", flush=True)
+    rm, rs, rJ, rJs = orc.svgp_exact_oracle_fast(Xq, Zp, Sigma, y, osc, ls)
+    nq = len(Xq)
+    gvar, gjvar = np.reshape(out["var"], (nq, T)), np.reshape(out["Jvar"], (nq, T, D))      # the library squeezes T = 1
+    vs, js = np.max(osc), np.max(osc[:, None] / ls[None, :] ** 2)
+    errs = {"mean": rel(out["mean"], rm), "var": float(np.max(np.abs(gvar - rs ** 2)) / vs), "J": rel(out["J"], rJ),
+            "Jvar": float(np.max(np.abs(gjvar - rJs ** 2)) / js)}
+    lim = {k: 1e-6 for k in errs}
+    if dtype:       # fp32: no worse than twice what the same algebra loses in numpy float32 (ill-conditioned K: cancellation)
+        m32, s32, J32, Js32 = orc.svgp_exact_oracle_fast(Xq, Zp, Sigma, y, osc, ls, dtype=np.float32)
+        ref32 = {"mean": rel(m32, rm), "var": float(np.max(np.abs(s32.astype(float) ** 2 - rs ** 2)) / vs), "J": rel(J32, rJ),
+                 "Jvar": float(np.max(np.abs(Js32.astype(float) ** 2 - rJs ** 2)) / js)}
+        lim = {k: max(2e-4, 2 * ref32[k]) for k in errs}
+    key = "fp32 " if dtype else "fp64 "
+    for k, v in errs.items():
+        worst2[key + k] = max(worst2.get(key + k, 0.0), v)
+    if any(errs[k] > lim[k] for k in errs) or not all(np.isfinite(list(errs.values()))):
+        bad2 += 1
+        print("LARGE:", tag, {k: f"{v:.2e}" for k, v in errs.items()}, flush=True)
+print(f"svgp: {max(cases // 2, 6)} cases, {bad2} flagged (limits 1e-6 fp64; fp32: max(2e-4, 2 x the numpy-float32 restatement's loss)); worst:",
+      {k: f"{v:.2e}" for k, v in sorted(worst2.items())})
+
