@@ -455,7 +455,6 @@ static int fit_impl(gpt_handle* h, const double* X, const double* Y, int64_t N, 
     h->committed = false;
     h->have_L = h->have_W = false;
     const Layout l = make_layout(N, D, O, 1, h->dtype_next);
-    predict_warmup(l.dtype);
     if (int rc = ensure_blob(h, l)) return rc;
     if (int rc = ensure_workspace(h, l.NP, l.npass)) return rc;
     const int NP = (int)l.NP;
@@ -513,7 +512,6 @@ int gpt_fit_svgp(gpt_handle* h, const double* Z, const double* y, const double* 
     h->committed = false;
     h->have_L = h->have_W = false;
     const Layout l = make_layout(N, D, T, T, dtype);
-    predict_warmup(l.dtype);
     if (int rc = ensure_blob(h, l)) return rc;
     if (int rc = ensure_workspace(h, l.NP, l.npass)) return rc;
     const int NP = (int)l.NP;

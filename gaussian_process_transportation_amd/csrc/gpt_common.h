@@ -108,7 +108,6 @@ hipError_t var_prepare(VarWorkspace& ws, hipStream_t s, const KernelParams& p, i
 void launch_var(hipStream_t s, const KernelParams& p, const VarWorkspace& ws, const void* Xs, const void* Wf,
                 const void* Xq, int64_t M, int ncomp, void* var, void* Jvar, void* dvar, const double* hdr);
 void var_release(VarWorkspace& ws);
-void predict_warmup(int dtype);          // first-use setup of the prediction kernels for this element type and device
 int var_workgroups();
 
 size_t wf_elems(int NP);          // elements of ONE task's tile set (+ prefetch overrun after the last task: wf_overrun_elems)

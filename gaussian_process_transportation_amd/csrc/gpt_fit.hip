@@ -798,7 +798,7 @@ static bool fit_aux_init(FitAux& aux) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, current_device()) != hipSuccess) return false;
     const int ncu = prop.multiProcessorCount;
-    int split = ncu / 2;
+    int split = ncu * 3 / 8;                             // CUs of the factorisation's second half (96 of 256: measured best of 64..160)
     if (const char* e = getenv("GPT_FIT_CHAIN_CUS")) split = atoi(e);
     if (split < 16 || split > ncu - 16) return false;
     const int words = (ncu + 31) / 32;
@@ -822,13 +822,14 @@ size_t factor_scratch_doubles(int NP) { return (size_t)NP * NP / 4 + (size_t)NP 
 // Serial form (NP < 4096, or no masked streams): Cholesky, finish, recursive-doubling inverse, one after the other in `s`.
 // Overlapped form: the second half of the Cholesky is bound by its launch chain (64 steps + thin updates: most CUs idle),
 // while the inverse of the first half and T21 = L21 W11 — 5/8 of the inverse's flops — need nothing but the first half's
-// columns, final by then.  So after the first half: the rest of the Cholesky runs on one half of the CUs, W11 and T21 on the
-// other; afterwards W22 and W21 = -W22 T21 on the whole chip.
+// columns, final by then.  So after the first half: the rest of the Cholesky runs on 3/8 of the CUs, W11 and T21 on the
+// others; afterwards W22 and W21 = -W22 T21 on the whole chip.  Measured (profiles/r02_fit_overlap.log): N = 8192 10.37 ->
+// 9.66 ms; N = 6000 and 12000 unchanged; N = 16384 slower (its second half is GEMM-bound, not chain-bound) — hence the size window.
 void launch_factor_inverse(hipStream_t s, double* K, double* W, int NP, int* info, double* scratch, FitAux* aux, hipEvent_t ev_factored) {
     const int nb = NP / NB;
     const int gw = potrf_group(NP) * potrf_outer_blocks();
     int hb = nb / 2 / gw * gw;                                      // split block column, group-aligned
-    const bool overlap = NP >= 4096 && hb >= gw && aux && fit_aux_init(*aux);
+    const bool overlap = NP > 4096 && NP <= 12288 && hb >= gw && aux && fit_aux_init(*aux);
     if (!overlap) {
         potrf_groups(s, K, W, NP, info, 0, nb);
         potrf_finish(s, K, W, NP, 0, nb);

@@ -706,9 +706,7 @@ __global__ __launch_bounds__(64) void k_var_finalize(KernelParams p, VarPlanDev 
     }
 }
 
-// Dynamic LDS beyond the default limit is an opt-in per kernel and device.  Also what loads this translation unit's code
-// object: called from the fit (predict_warmup), so that the first predict of a process does not pay for it (13 ms once,
-// profiles/r02_first_call_latency.log).
+// Dynamic LDS beyond the default limit is an opt-in per kernel and device.
 template <typename T>
 static void var_kernel_setup() {
     static PerDeviceOnce once;
@@ -718,10 +716,6 @@ static void var_kernel_setup() {
                          reinterpret_cast<const void*>(k_var<T, 1, false, KT_MATERN12>),
                          reinterpret_cast<const void*>(k_var<T, 1, false, KT_MATERN32>), reinterpret_cast<const void*>(k_var<T, 1, false, KT_MATERN52>)};
     for (const void* f : fns) hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)var_lds_bytes<T>());
-}
-
-void predict_warmup(int dtype) {
-    if (dtype == DT_F32) var_kernel_setup<float>(); else var_kernel_setup<double>();
 }
 
 template <typename T>

@@ -15,7 +15,6 @@ static void touch_r(const void* p, size_t bytes) {
     acc = acc + b[0]; acc = acc + b[bytes - 1]; acc = acc + b[bytes / 2];
 }
 
-void predict_warmup(int) {}
 size_t wf_elems(int NP) { const size_t nb = NP / WT; return nb * (nb + 1) / 2 * WT_TILE_DOUBLES; }
 size_t wf_overrun_elems() { return WT_STEP_DOUBLES; }
 

@@ -961,3 +961,38 @@ def test_svgp_transport_attribute_protocol(dtype, tol):
                             quaternion_multiply(quaternion_from_nonorthogonal(aff.rotation_matrix), ori))
     assert_parity(tr.training_ori, q, 10 * tol, "training_ori")
     assert np.allclose(np.linalg.norm(tr.training_ori, axis=1), 1.0, atol=1e-6)
+
+
+@pytest.mark.parametrize("N", [4700, 5300])
+def test_overlapped_factor_and_inverse(N, monkeypatch):
+    """For 4096 < NP <= 12288 the second half of the Cholesky runs on 3/8 of the CUs while W11 = L11^-1 and L21 W11 are
+    computed on the others (CU-masked streams, gpt_fit.hip:launch_factor_inverse).  L against LAPACK, W L = I, alpha, the
+    pivot of a matrix that stops being positive definite in the SECOND half, and the serial form (GPT_FIT_OVERLAP=0)."""
+    import scipy.linalg
+    import scipy.linalg.lapack
+    from gaussian_process_transportation_amd import _lib
+    from oracle import gp_oracle as orc
+    rng = np.random.default_rng(N)
+    X = rng.uniform(0, 1, (N, 3))
+    Y = np.sin(3 * X[:, :2])
+    ls, c, noise, jit = np.array([0.25, 0.3, 0.2]), 0.7, 1e-3, 1e-10
+    Kref = c * orc.rbf_gram(X / ls) + (noise + jit) * np.eye(N)
+    Lref = np.linalg.cholesky(Kref)
+    aref = scipy.linalg.cho_solve((Lref, True), Y)
+    for overlap in ("1", "0"):
+        monkeypatch.setenv("GPT_FIT_OVERLAP", overlap)
+        h = _lib.Handle(0)                                   # the environment is read when a handle first factorises
+        h.fit(X, Y, ls, c, noise, jit)
+        L, alpha = h.export()
+        assert_parity(L, Lref, 1e-11, f"L_ (overlap {overlap})")
+        assert_parity(alpha, aref, 1e-7, f"alpha_ (overlap {overlap})")
+        W = h.export_inverse_factor()
+        assert np.abs(W @ Lref - np.eye(N)).max() < 1e-9
+        h.fit(X, Y, ls, c, noise, jit)                       # streams and events are reused by the next fit
+        assert np.array_equal(h.export()[0], L)
+        Sigma = 1e-3 * np.eye(N)
+        Sigma[N - 700, N - 700] = -2.0
+        with pytest.raises(np.linalg.LinAlgError) as ei:
+            h.fit_noise_matrix(X, Y, ls, c, Sigma)
+        assert int(str(ei.value).split("pivot")[1].split()[0]) == N - 700 + 1
+        h.close()
