@@ -618,8 +618,11 @@ int gpt_predict_all(gpt_handle* h, const void* Xq_, int64_t M, void* mean_, void
     for (int b = 0; b < (nchunks > 1 ? 2 : 1); ++b)
         for (int i = 0; i < ST_COUNT; ++i)
             if (want[i]) { if (int rc = ensure_stage(h, b, i, (size_t)cap * per[i] * esz)) return rc; }
-    if (int rc = ensure_copy_stream(h)) return rc;
-    hipStream_t s = h->stream, cs = h->copy_stream;
+    // one chunk (the reference's own batch sizes): queries in, kernels, results out, all in the handle's stream — no second
+    // stream, no events; several chunks: the results of chunk i leave on the copy stream while chunk i + 1 computes
+    const bool single = nchunks == 1;
+    if (!single) { if (int rc = ensure_copy_stream(h)) return rc; }
+    hipStream_t s = h->stream, cs = single ? h->stream : h->copy_stream;
     // chunk i computes on `s` in staging set i & 1; its outputs leave on `cs` while chunk i + 1 computes
     auto enqueue = [&](int64_t i) -> int {
         const int b = (int)(i & 1);
@@ -630,14 +633,14 @@ int gpt_predict_all(gpt_handle* h, const void* Xq_, int64_t M, void* mean_, void
         if (int rc = gpt_predict_all_dev(h, t.buf[ST_Q], m, mean ? t.buf[ST_MEAN] : nullptr, var ? t.buf[ST_VAR] : nullptr,
                                          J ? t.buf[ST_J] : nullptr, Jvar ? t.buf[ST_JVAR] : nullptr, dvar ? t.buf[ST_DVAR] : nullptr))
             return rc;
-        HIPCHK(hipEventRecord(h->ev_done[b], s));
+        if (!single) HIPCHK(hipEventRecord(h->ev_done[b], s));
         return GPT_OK;
     };
     auto copy_out = [&](int64_t i) -> int {
         const int b = (int)(i & 1);
         const int64_t off = i * cap, m = (M - off) < cap ? (M - off) : cap;
         const gpt_handle::Staging& t = h->st[b];
-        HIPCHK(hipStreamWaitEvent(cs, h->ev_done[b], 0));
+        if (!single) HIPCHK(hipStreamWaitEvent(cs, h->ev_done[b], 0));
         unsigned char* const dst[ST_COUNT] = {nullptr, mean, var, J, Jvar, nullptr};
         for (int k = ST_MEAN; k <= ST_JVAR; ++k)
             if (dst[k]) HIPCHK(hipMemcpyAsync(dst[k] + (size_t)off * per[k] * esz, t.buf[k], (size_t)m * per[k] * esz, hipMemcpyDeviceToHost, cs));
@@ -645,7 +648,7 @@ int gpt_predict_all(gpt_handle* h, const void* Xq_, int64_t M, void* mean_, void
             for (size_t d = 0; d < D; ++d)   // device chunk is (D, m); host result is (D, M)
                 HIPCHK(hipMemcpyAsync(dvar + (d * (size_t)M + (size_t)off) * esz, static_cast<unsigned char*>(t.buf[ST_DVAR]) + d * (size_t)m * esz,
                                       (size_t)m * esz, hipMemcpyDeviceToHost, cs));
-        HIPCHK(hipEventRecord(h->ev_copied[b], cs));
+        if (!single) HIPCHK(hipEventRecord(h->ev_copied[b], cs));
         return GPT_OK;
     };
     if (int rc = enqueue(0)) return rc;
@@ -653,7 +656,7 @@ int gpt_predict_all(gpt_handle* h, const void* Xq_, int64_t M, void* mean_, void
         if (i + 1 < nchunks) { if (int rc = enqueue(i + 1)) return rc; }   // queued before chunk i's (host-blocking) copies
         if (int rc = copy_out(i)) return rc;
     }
-    HIPCHK(hipStreamSynchronize(cs));
+    if (!single) HIPCHK(hipStreamSynchronize(cs));
     HIPCHK(hipStreamSynchronize(s));
     return GPT_OK;
 }

@@ -884,6 +884,14 @@ def test_fp32_exact_gp_model():
     assert_parity(s32, np.repeat((np.sqrt(var) - np.sqrt(noise))[:, None], 3, axis=1), 5e-3, "std (GaussianProcess, fp32)")
     with pytest.raises(_lib.GptError):
         gp.predict(Xq[:5], return_cov=True)                     # covariance / samples: fp64 models only
+    # host-buffer path across the 131072-query chunk boundary (two staging sets, copy stream) in the 4-byte element type
+    big = np.random.default_rng(8).uniform(-0.1, 1.1, (140_000, 3))
+    full = gp._handle.predict_all(big, mean=True, var=True, J=True, Jvar=True)
+    for a, b in ((0, 700), (130_900, 131_300), (139_500, 140_000)):
+        part = gp._handle.predict_all(big[a:b], mean=True, var=True, J=True, Jvar=True)
+        assert np.array_equal(part["mean"], full["mean"][a:b]) and np.array_equal(part["J"], full["J"][a:b])
+        assert_parity(part["var"], full["var"][a:b], 1e-4, "var across chunks (fp32)")
+        assert_parity(part["Jvar"], full["Jvar"][a:b], 1e-4, "Jvar across chunks (fp32)")
 
 
 def test_callable_optimizer_follows_sklearn_protocol():
