@@ -59,7 +59,8 @@ class SVGPExactPredictor:
         return out["mean"], np.sqrt(out["var"]), out["J"], np.sqrt(np.maximum(out["Jvar"], 0))
 
     def posterior_f(self, x, return_std=False):
-        """mean (M,T) [, std (M,T)]  (:113-129)."""
+        """mean (M,T) [, std (M,T)]  (:113-129).  (The reference's mean-only branch returns (T,M): it skips the permute
+        of :125; here both branches use the (M,T) layout its callers rely on.)"""
         out = self._handle.predict_all(x, mean=True, var=bool(return_std))
         if not return_std:
             return out["mean"]
