@@ -44,6 +44,8 @@ SIGNATURES = {
     "gpt_export_inverse_factor": (C.c_int, [_vp, _dp]),
     "gpt_lml": (C.c_int, [_vp, _dp]),
     "gpt_lml_gradient": (C.c_int, [_vp, _dp, _dp]),
+    "gpt_lml_objective": (C.c_int, [_vp, _dp, _dp, _i64, C.c_int, C.c_int, _dp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int,
+                                    _dp, _dp]),
     "gpt_factor_blob": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
     "gpt_factor_alloc": (C.c_int, [_vp, _i64, C.c_int, C.c_int, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
     "gpt_factor_alloc_model": (C.c_int, [_vp, _i64, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
@@ -266,6 +268,18 @@ class Handle:
         v = C.c_double()
         g = np.zeros(2 + int(n_ls))
         check(self.lib.gpt_lml_gradient(self._h, C.byref(v), dptr(g)), "gpt_lml_gradient")
+        return v.value, g
+
+    def lml_objective(self, X, Y, length_scale, constant_value, noise_level, alpha, kernel_type=0):
+        """(lml, gradient w.r.t. theta = log [c, length_scale..., noise]) for these hyper-parameters in one call; the
+        handle holds no model afterwards.  X, Y as for fit (validated by the caller once: the optimizer calls this
+        hundreds of times on the same arrays)."""
+        ls = np.ascontiguousarray(np.atleast_1d(length_scale), dtype=np.float64)
+        v = C.c_double()
+        g = np.zeros(2 + ls.size)
+        N, D = X.shape
+        check(self.lib.gpt_lml_objective(self._h, dptr(X), dptr(Y), N, D, Y.shape[1], dptr(ls), ls.size, float(constant_value),
+                                         float(noise_level), float(alpha), int(kernel_type), C.byref(v), dptr(g)), "gpt_lml_objective")
         return v.value, g
 
     def fit_timings(self):

@@ -161,6 +161,7 @@ struct gpt_handle {
     int ws_npass = 0;
     bool have_L = false;           // dK holds L of the committed model (gpt_export, gpt_lml)
     bool have_W = false;           // dW holds L^-1 of the committed model (gpt_predict_cov, gpt_lml_gradient, gpt_export_inverse_factor)
+    bool objective_ready = false;  // gpt_lml_objective: factor and alpha in the workspace, no committed model
     std::vector<double> hostY;     // filtered targets (N,O) for the LML
     // staging of the host-pointer API, grow-only per buffer
     // (two sets: while the results of one chunk travel to the host on `copy_stream`, the next chunk computes)
@@ -417,7 +418,7 @@ int gpt_fit(gpt_handle* h, const double* X, const double* Y, int64_t N, int D, i
 
 static int fit_impl(gpt_handle* h, const double* X, const double* Y, int64_t N, int D, int O,
                     const double* length_scale, int n_ls, double constant_value, double noise_level,
-                    double alpha_jitter, int kernel_type, const double* Sigma);
+                    double alpha_jitter, int kernel_type, const double* Sigma, bool model = true);
 
 int gpt_fit_kernel(gpt_handle* h, const double* X, const double* Y, int64_t N, int D, int O,
                    const double* length_scale, int n_ls, double constant_value, double noise_level,
@@ -443,9 +444,11 @@ static int read_fit_times(gpt_handle* h) {
     return GPT_OK;
 }
 
+// model = false: what one evaluation of the optimizer's objective needs (L, W, alpha in the fp64 workspace) and nothing of the
+// prediction-side model (no alpha / W in the blob's layouts): the handle is left without a committed model.
 static int fit_impl(gpt_handle* h, const double* X, const double* Y, int64_t N, int D, int O,
                     const double* length_scale, int n_ls, double constant_value, double noise_level,
-                    double alpha_jitter, int kernel_type, const double* Sigma) {
+                    double alpha_jitter, int kernel_type, const double* Sigma, bool model) {
     if (!h || !X || !Y || !length_scale) return fail(GPT_E_ARG, "gpt_fit: NULL argument");
     if (kernel_type < GPT_KERNEL_RBF || kernel_type > GPT_KERNEL_MATERN52) return fail(GPT_E_ARG, "gpt_fit: unknown kernel_type");
     if (int rc = check_geometry("gpt_fit", N, D, O, length_scale, n_ls)) return rc;
@@ -454,6 +457,7 @@ static int fit_impl(gpt_handle* h, const double* X, const double* Y, int64_t N, 
     if (int rc = set_device(h)) return rc;
     h->committed = false;
     h->have_L = h->have_W = false;
+    h->objective_ready = false;
     const Layout l = make_layout(N, D, O, 1, h->dtype_next);
     if (int rc = ensure_blob(h, l)) return rc;
     if (int rc = ensure_workspace(h, l.NP, l.npass)) return rc;
@@ -478,11 +482,13 @@ static int fit_impl(gpt_handle* h, const double* X, const double* Y, int64_t N, 
     for (int ps = 0; ps < l.npass; ++ps) {
         double* a64 = h->dA64 + (size_t)ps * NP * 4;
         launch_alpha(s, h->dW, h->dY4 + (size_t)ps * NP * 4, (int)N, NP, h->dT4, a64, h->dScr);
-        launch_store4(s, a64, NP, static_cast<unsigned char*>(h->dA4()) + (size_t)ps * NP * 4 * l.esz, l.dtype, 0, 0, 4, 1.0);
+        if (model) launch_store4(s, a64, NP, static_cast<unsigned char*>(h->dA4()) + (size_t)ps * NP * 4 * l.esz, l.dtype, 0, 0, 4, 1.0);
     }
     HIPCHK(hipEventRecord(h->ev[4], s));
-    launch_pack_w(s, h->dW, (int)N, NP, h->dWf(), l.dtype, 0, 1.0);
-    HIPCHK(hipMemsetAsync(static_cast<unsigned char*>(h->dWf()) + wf_elems(NP) * l.esz, 0, wf_overrun_elems() * l.esz, s));
+    if (model) {
+        launch_pack_w(s, h->dW, (int)N, NP, h->dWf(), l.dtype, 0, 1.0);
+        HIPCHK(hipMemsetAsync(static_cast<unsigned char*>(h->dWf()) + wf_elems(NP) * l.esz, 0, wf_overrun_elems() * l.esz, s));
+    }
     HIPCHK(hipEventRecord(h->ev[5], s));
     HIPCHK(hipGetLastError());
     int info = 0;
@@ -494,9 +500,19 @@ static int fit_impl(gpt_handle* h, const double* X, const double* Y, int64_t N, 
         snprintf(buf, sizeof buf, "gpt_fit: kernel matrix is not positive definite (pivot %d <= 0)", info);
         return fail(GPT_E_NOT_PD, buf);
     }
-    h->committed = true;
+    h->committed = model;
+    h->objective_ready = !model;
     h->have_L = h->have_W = true;
     return GPT_OK;
+}
+
+int gpt_lml_objective(gpt_handle* h, const double* X, const double* Y, int64_t N, int D, int O,
+                      const double* length_scale, int n_ls, double constant_value, double noise_level,
+                      double alpha_jitter, int kernel_type, double* lml, double* grad) {
+    if (!lml || !grad) return fail(GPT_E_ARG, "gpt_lml_objective: NULL argument");
+    if (int rc = fit_impl(h, X, Y, N, D, O, length_scale, n_ls, constant_value, noise_level, alpha_jitter, kernel_type, nullptr, false))
+        return rc;
+    return gpt_lml_gradient(h, lml, grad);
 }
 
 int gpt_fit_svgp(gpt_handle* h, const double* Z, const double* y, const double* Sigma, int64_t N, int D, int T,
@@ -511,6 +527,7 @@ int gpt_fit_svgp(gpt_handle* h, const double* Z, const double* y, const double* 
     if (int rc = set_device(h)) return rc;
     h->committed = false;
     h->have_L = h->have_W = false;
+    h->objective_ready = false;
     const Layout l = make_layout(N, D, T, T, dtype);
     if (int rc = ensure_blob(h, l)) return rc;
     if (int rc = ensure_workspace(h, l.NP, l.npass)) return rc;
@@ -730,7 +747,7 @@ int gpt_export_inverse_factor(gpt_handle* h, double* W) {
 
 int gpt_lml(gpt_handle* h, double* lml) {
     if (!h || !lml) return fail(GPT_E_ARG, "gpt_lml: NULL argument");
-    if (!h->committed || !h->have_L || !h->have_W) return fail(GPT_E_STATE, "gpt_lml: needs the handle that ran gpt_fit");
+    if (!(h->committed || h->objective_ready) || !h->have_L || !h->have_W) return fail(GPT_E_STATE, "gpt_lml: needs the handle that ran gpt_fit");
     if (int rc = set_device(h)) return rc;
     const int64_t N = h->p.N, NP = h->p.NP;
     const int O = h->p.O;
@@ -790,7 +807,7 @@ int gpt_predict_cov(gpt_handle* h, const double* Xq, int64_t M, double* mean, do
 
 int gpt_lml_gradient(gpt_handle* h, double* lml, double* grad) {
     if (!h || !lml || !grad) return fail(GPT_E_ARG, "gpt_lml_gradient: NULL argument");
-    if (!h->committed || !h->have_L || !h->have_W) return fail(GPT_E_STATE, "gpt_lml_gradient: needs the handle that ran gpt_fit");
+    if (!(h->committed || h->objective_ready) || !h->have_L || !h->have_W) return fail(GPT_E_STATE, "gpt_lml_gradient: needs the handle that ran gpt_fit");
     if (int rc = gpt_lml(h, lml)) return rc;                    // uses diag(L) in dK before it is overwritten
     const int64_t N = h->p.N, NP = h->p.NP;
     const int D = h->p.D, O = h->p.O;
@@ -839,6 +856,7 @@ int gpt_factor_alloc_model(gpt_handle* h, int64_t N, int D, int O, int n_tasks, 
     if (int rc = set_device(h)) return rc;
     h->committed = false;
     h->have_L = h->have_W = false;
+    h->objective_ready = false;
     if (int rc = ensure_blob(h, make_layout(N, D, O, n_tasks, dtype))) return rc;
     *dev_ptr = h->blob;
     *bytes = h->lay.total;

@@ -8,7 +8,7 @@ starting points drawn log-uniformly inside the kernel's bounds with the GLOBAL n
 
 Here the driver is the same (scipy's L-BFGS-B on the host — or the caller's own `optimizer(obj_func,
 initial_theta, bounds)` callable, sklearn's protocol — same bounds, same RNG draws in the same order); every objective evaluation — Gram, Cholesky, alpha, K^-1 and the traces of the gradient
-(_gpr.py:537-652) — runs on the GPU (`gpt_fit` + `gpt_lml_gradient`).  The scikit-learn kernel object is
+(_gpr.py:537-652) — runs on the GPU (`gpt_lml_objective`).  The scikit-learn kernel object is
 used only as the container of theta / bounds / fixed flags."""
 from __future__ import annotations
 
@@ -54,13 +54,14 @@ def optimize_hyperparameters(gp, c0, ls0, noise0):
     h = gp._handle
     n_ls = int(np.size(ls0))
     free = _free_mask(kernel, n_ls)
-    X, Y, jitter = gp.X, gp.Y, gp.alpha
+    jitter = gp.alpha
+    X = _lib.as_f64(gp.X, 2, "X")                          # validated once; every evaluation reuses these arrays
+    Y = _lib.as_f64(gp.Y, 2, "y")
 
     def objective(theta):
         c, ls, noise = _unpack(kernel, theta)
         try:
-            h.fit(X, Y, ls, c, noise, jitter, gp._ktype)
-            lml, grad = h.lml_gradient(n_ls)
+            lml, grad = h.lml_objective(X, Y, ls, c, noise, jitter, gp._ktype)     # one C call, no prediction-side model
         except np.linalg.LinAlgError:                      # _gpr.py:587-590: -inf LML, zero gradient
             return np.inf, np.zeros_like(theta)
         return -lml, -grad[free]

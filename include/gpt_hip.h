@@ -159,6 +159,14 @@ int gpt_lml(gpt_handle* h, double* lml);
  * factor held for gpt_export (a later gpt_fit restores it). */
 int gpt_lml_gradient(gpt_handle* h, double* lml, double* grad);
 
+/* One evaluation of the optimizer's objective in one call: what gpt_fit_kernel + gpt_lml_gradient return for these
+ * hyper-parameters, without building the prediction-side model (no packed inverse factor, no alpha in the model's
+ * layout) — the inner loop of GaussianProcess.fit with optimizer='fmin_l_bfgs_b' (sklearn/_gpr.py:296-338: every
+ * L-BFGS-B step evaluates the LML and its gradient).  Afterwards the handle holds NO model (predict needs a gpt_fit). */
+int gpt_lml_objective(gpt_handle* h, const double* X, const double* Y, int64_t N, int D, int O,
+                      const double* length_scale, int n_ls, double constant_value, double noise_level,
+                      double alpha_jitter, int kernel_type, double* lml, double* grad);
+
 /* Multi-GPU hand-off of a fitted model (fit on rank 0, predict shards everywhere).  The model
  * is one contiguous device blob {header, scaled X, alpha, packed L^-1}:
  *   rank 0   : gpt_fit(...); gpt_factor_blob(h, &ptr, &bytes)

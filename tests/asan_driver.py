@@ -40,6 +40,14 @@ for N, D, O in ((1, 1, 1), (700, 3, 3), (1100, 2, 6)):
         if dtype == _lib.GPT_F64:
             h.predict_cov(rng.uniform(0, 1, (130, D)))
         h.lml_gradient(D)
+        h.lml_objective(X, Y, np.full(D, 0.3), 1.0, 1e-2, 1e-10)       # leaves no model behind
+        try:
+            h.predict_all(rng.uniform(0, 1, (3, D)), mean=True)
+            raise AssertionError("predict after gpt_lml_objective must fail")
+        except _lib.GptError:
+            pass
+        h.fit(X, Y, np.full(D, 0.3), 1.0, 1e-2, 1e-10)
+        h.lml_gradient(D)
         try:
             h.export(want_alpha=False)                      # L was overwritten by the gradient's K^-1
             raise AssertionError("export of L after lml_gradient must fail")

@@ -1004,3 +1004,24 @@ def test_overlapped_factor_and_inverse(N, monkeypatch):
             h.fit_noise_matrix(X, Y, ls, c, Sigma)
         assert int(str(ei.value).split("pivot")[1].split()[0]) == N - 700 + 1
         h.close()
+
+
+def test_lml_objective_is_fit_plus_gradient_without_a_model():
+    """gpt_lml_objective (the optimizer's inner loop: one C call, no packed model) returns exactly what gpt_fit_kernel +
+    gpt_lml_gradient return, and leaves the handle without a model."""
+    from gaussian_process_transportation_amd import _lib
+    g = load_golden("synthetic_3d_N256")
+    X, Y = g["X"], g["Y"]
+    h = _lib.Handle(0)
+    for ls, c, noise, kt in ((np.array([0.1, 0.1, 0.1]), 0.1, 1e-4, 0), (np.array([0.3]), 0.5, 1e-3, 0), (np.array([0.2, 0.3, 0.4]), 0.2, 1e-3, 2)):
+        h.fit(X, Y, ls, c, noise, 1e-10, kt)
+        v0, g0 = h.lml_gradient(ls.size)
+        v1, g1 = h.lml_objective(X, Y, ls, c, noise, 1e-10, kt)
+        assert v0 == v1 and np.array_equal(g0, g1)
+        with pytest.raises(_lib.GptError):
+            h.predict_all(g["Xq"], mean=True)
+    h.fit(X, Y, np.array([0.1, 0.1, 0.1]), 0.1, 1e-4, 1e-10)
+    assert_parity(h.predict_all(g["Xq"], mean=True)["mean"], g["mean"], RTOL, "mean after a real fit")
+    with pytest.raises(np.linalg.LinAlgError):
+        h.lml_objective(np.vstack([X, X[:5]]), np.vstack([Y, Y[:5]]), np.array([0.1]), 1.0, 0.0, 0.0)
+    h.close()
