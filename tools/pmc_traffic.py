@@ -1,7 +1,8 @@
 """Turn the PMC passes of tools/gpu_pmc.sh (run on the GPU box, merged back under gpurun_out/) into the record bench.py
 quotes as `roofline.traffic`: HBM-side bytes per launch of the dominant kernel.
 
-    python tools/pmc_traffic.py gpurun_out/<tag> j 8192 500000        # key (j | jvar | svgp), n_source, queries per launch
+    python tools/pmc_traffic.py gpurun_out/<tag> j 8192 500000 [commit]   # key (j | jvar | svgp), n_source, queries per launch,
+                                                                          # commit the GPU run was made from (default: HEAD)
 
 FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE reports exactly half of the bytes of wide (16 B per lane)
 coalesced streaming reads — /opt/skills/guides/MI355X_MICROARCH.md, section HBM: "double it before comparing with a byte
@@ -39,7 +40,8 @@ def main():
     rec = {"n_source": n_source, "queries": queries,
            "hbm_bytes_per_launch": (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0,
            "fetch_size_kib": c["FETCH_SIZE"], "write_size_kib": c["WRITE_SIZE"],
-           "commit": subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip(),
+           "commit": sys.argv[5] if len(sys.argv) > 5 else
+           subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip(),
            "source": os.path.relpath(d, ROOT)}
     if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
         rec["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
