@@ -395,7 +395,7 @@ __global__ __launch_bounds__(256) void k_potrf_step(double* __restrict__ K, doub
 }
 
 // After the last step: for every diagonal block, move the parked L11 from W into K (zeros above the diagonal)
-// and leave inv(L11) in W (the seed of launch_trinv).  One workgroup per block, all blocks in one launch.
+// and leave inv(L11) in W (the seed of trinv_levels).  One workgroup per block; blocks [b0, b0 + gridDim.x).
 __global__ __launch_bounds__(256) void k_potrf_finish(double* __restrict__ K, double* __restrict__ W, int NP, int b0) {
     __shared__ double dinv[NB];
     extern __shared__ __attribute__((aligned(16))) double smem[];
