@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("GPT_HIP_LIB") or os.path.join(_HERE, "libgpt_hip.so")
 
 GPT_OK, GPT_E_HIP, GPT_E_NOT_PD, GPT_E_ARG, GPT_E_STATE = 0, -1, -2, -3, -4
 GPT_F64, GPT_F32 = 0, 1
+MAX_D = 8          # input dimensions the library accepts (gpt_common.h: D <= 3 tuned layout, 4 .. 8 wide layout)
 _NP_DTYPE = {GPT_F64: np.float64, GPT_F32: np.float32}
 
 _dp = C.POINTER(C.c_double)
@@ -202,8 +203,8 @@ class Handle:
         N, D = X.shape
         if Y.shape[0] != N:
             raise ValueError("X and Y have different numbers of rows")
-        if not 1 <= D <= 3:
-            raise ValueError(f"X has {D} features: this GPU path supports input dimension D = 1, 2 or 3 only")
+        if not 1 <= D <= MAX_D:
+            raise ValueError(f"X has {D} features: this GPU path supports input dimension D = 1 .. {MAX_D} only")
         check(self.lib.gpt_fit_kernel(self._h, dptr(X), dptr(Y), N, D, Y.shape[1], dptr(ls), ls.size,
                                       float(constant_value), float(noise_level), float(alpha), int(kernel_type)), "gpt_fit")
 

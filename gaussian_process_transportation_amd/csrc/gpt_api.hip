@@ -34,10 +34,13 @@ constexpr double MAGIC = 1196446770.0;   // "GPT2": header layout of this versio
 constexpr int HDR_DOUBLES = 64;
 constexpr int HDR_TASK_C = 16;           // hdr[16 + t]: prior variance of task t (constant_value / outputscale)
 constexpr int MAX_TASKS = 32;
+constexpr int HDR_LS = 8;                // hdr[8 + d], d < 3: length-scale of dimension d
+constexpr int HDR_LS_HI = 48;            // hdr[48 + d - 3], 3 <= d < MAX_D: the further dimensions of the wide layout
+inline int hdr_ls_slot(int d) { return d < 3 ? HDR_LS + d : HDR_LS_HI + d - 3; }
 constexpr int64_t HOST_CHUNK = 1 << 17;  // queries per chunk of the host-pointer API (two chunks in flight)
 
-// Model blob: [header: 64 doubles][Xs: NP x 4][A4: npass x NP x 4][Wf: ntask tile sets + overrun], the three arrays
-// in the model's element type.  Offsets in bytes.
+// Model blob: [header: 64 doubles][Xs: NP x 4 (D <= 3) or NP x 8][A4: npass x NP x 4][Wf: ntask tile sets + overrun],
+// the three arrays in the model's element type.  Offsets in bytes.
 struct Layout {
     int64_t N = 0, NP = 0;
     int D = 0, O = 0, npass = 0, ntask = 1, dtype = DT_F64;
@@ -52,7 +55,7 @@ Layout make_layout(int64_t N, int D, int O, int ntask, int dtype) {
     l.NP = (N + PAD_N - 1) / PAD_N * PAD_N;
     l.npass = (O + 3) / 4;
     l.off_xs = HDR_DOUBLES * sizeof(double);
-    l.off_a4 = l.off_xs + (size_t)l.NP * 4 * l.esz;
+    l.off_a4 = l.off_xs + (size_t)l.NP * xs_stride(D) * l.esz;
     l.off_wf = l.off_a4 + (size_t)l.npass * l.NP * 4 * l.esz;
     l.total = l.off_wf + ((size_t)ntask * wf_elems((int)l.NP) + wf_overrun_elems()) * l.esz;
     return l;
@@ -80,7 +83,8 @@ int var_workgroups() {
     return n[dev];
 }
 
-static int var_cols_per_query(const KernelParams& p, int ncomp) { return (ncomp == 3) ? p.D : ncomp; }   // 3 = Jacobian variance alone
+// ncomp: 1 = k* alone; 3 = Jacobian variance alone, D columns per query (D <= 3); 4 / 8 / 16 = var_fused_cols(D)
+static int var_cols_per_query(const KernelParams& p, int ncomp) { return (ncomp == 3) ? p.D : ncomp; }
 
 void var_release(VarWorkspace& ws) {
     for (void** pp : {&ws.slab, &ws.vslab, &ws.bscratch, &ws.plan_dev}) { if (*pp) (void)hipFree(*pp); *pp = nullptr; }
@@ -151,7 +155,7 @@ struct gpt_handle {
     Layout lay{};
     bool have_layout = false, committed = false;
     KernelParams p{};
-    double jitter = 0, ls[3] = {1, 1, 1};
+    double jitter = 0, ls[MAX_D] = {1, 1, 1, 1, 1, 1, 1, 1};
     int n_ls = 1;
     // fit workspace (fp64)
     double *dK = nullptr, *dW = nullptr, *dY4 = nullptr, *dT4 = nullptr, *dTa = nullptr, *dXs64 = nullptr, *dA64 = nullptr, *dscal = nullptr;
@@ -230,8 +234,8 @@ int ensure_workspace(gpt_handle* h, int64_t NP, int npass) {
     HIPCHK(hipMalloc(&h->dA64, (size_t)npass * NP * 4 * sizeof(double)));
     HIPCHK(hipMalloc(&h->dT4, (size_t)NP * 4 * sizeof(double)));
     HIPCHK(hipMalloc(&h->dTa, (size_t)NP * 4 * sizeof(double)));
-    HIPCHK(hipMalloc(&h->dXs64, (size_t)NP * 4 * sizeof(double)));
-    HIPCHK(hipMalloc(&h->dscal, 8 * sizeof(double)));
+    HIPCHK(hipMalloc(&h->dXs64, (size_t)NP * MAX_D * sizeof(double)));
+    HIPCHK(hipMalloc(&h->dscal, 16 * sizeof(double)));
     HIPCHK(hipMalloc(&h->dinfo, sizeof(int)));
     {
         const size_t a = factor_scratch_doubles((int)NP), b = (size_t)(NP / 512) * NP * 4;
@@ -274,15 +278,15 @@ void fill_params(gpt_handle* h, const double* hdr) {
     p.dtype = (int)hdr[15];
     h->jitter = hdr[7];
     h->n_ls = (int)hdr[11];
-    for (int d = 0; d < 3; ++d) {
-        h->ls[d] = hdr[8 + d];
-        p.inv_ls[d] = (d < p.D) ? 1.0 / hdr[8 + d] : 0.0;
+    for (int d = 0; d < MAX_D; ++d) {
+        h->ls[d] = (d < p.D) ? hdr[hdr_ls_slot(d)] : 1.0;
+        p.inv_ls[d] = (d < p.D) ? 1.0 / hdr[hdr_ls_slot(d)] : 0.0;
     }
 }
 
 int check_geometry(const char* who, int64_t N, int D, int O, const double* length_scale, int n_ls) {
     if (N < 1 || N > (1 << 20)) return fail(GPT_E_ARG, std::string(who) + ": N out of range");
-    if (D < 1 || D > 3) return fail(GPT_E_ARG, std::string(who) + ": D must be 1, 2 or 3");
+    if (D < 1 || D > MAX_D) return fail(GPT_E_ARG, std::string(who) + ": D must be 1 .. 8");
     if (O < 1) return fail(GPT_E_ARG, std::string(who) + ": O must be >= 1");
     if (n_ls != 1 && n_ls != D) return fail(GPT_E_ARG, std::string(who) + ": length_scale must have 1 or D entries");
     for (int d = 0; d < n_ls; ++d)
@@ -297,13 +301,15 @@ int upload_sources(gpt_handle* h, const Layout& l, const double* X, std::vector<
     hdr.assign(HDR_DOUBLES, 0.0);
     hdr[0] = MAGIC; hdr[1] = (double)l.N; hdr[2] = (double)l.NP; hdr[3] = l.D; hdr[4] = l.O;
     hdr[5] = constant_value; hdr[6] = noise_level; hdr[7] = alpha_jitter;
-    for (int d = 0; d < 3; ++d) hdr[8 + d] = (d < l.D) ? length_scale[n_ls == 1 ? 0 : d] : 1.0;
+    for (int d = 0; d < 3; ++d) hdr[HDR_LS + d] = 1.0;
+    for (int d = 0; d < l.D; ++d) hdr[hdr_ls_slot(d)] = length_scale[n_ls == 1 ? 0 : d];
     hdr[11] = n_ls; hdr[12] = l.npass; hdr[13] = kernel_type; hdr[14] = l.ntask; hdr[15] = l.dtype;
     fill_params(h, hdr.data());
     const size_t NP = (size_t)l.NP;
-    std::vector<double> xs(NP * 4, 0.0);
+    const size_t XS = (size_t)xs_stride(l.D);
+    std::vector<double> xs(NP * XS, 0.0);
     for (int64_t i = 0; i < l.N; ++i)
-        for (int d = 0; d < l.D; ++d) xs[(size_t)i * 4 + d] = X[i * l.D + d] * h->p.inv_ls[d];
+        for (int d = 0; d < l.D; ++d) xs[(size_t)i * XS + d] = X[i * l.D + d] * h->p.inv_ls[d];
     hipStream_t s = h->stream;
     HIPCHK(hipMemcpyAsync(h->dXs64, xs.data(), xs.size() * sizeof(double), hipMemcpyHostToDevice, s));
     if (l.dtype == DT_F32) {
@@ -322,7 +328,7 @@ int factorise(gpt_handle* h, int64_t N, int NP, int kernel_type, double c, doubl
     hipStream_t s = h->stream;
     HIPCHK(hipMemsetAsync(h->dinfo, 0, sizeof(int), s));
     HIPCHK(hipMemsetAsync(h->dW, 0, (size_t)NP * NP * sizeof(double), s));
-    launch_gram(s, h->dXs64, (int)N, NP, kernel_type, c, diag_add, h->dK);
+    launch_gram(s, h->dXs64, h->p.D, (int)N, NP, kernel_type, c, diag_add, h->dK);
     if (Sigma) {      // K += Sigma: staged through dW (not in use until the factorisation starts)
         HIPCHK(hipMemcpyAsync(h->dW, Sigma, (size_t)N * N * sizeof(double), hipMemcpyHostToDevice, s));
         launch_add_lower(s, h->dK, h->dW, (int)N, NP);
@@ -581,7 +587,7 @@ int gpt_reserve(gpt_handle* h, int64_t M, int jacobian_variance) {
     if (M < 0) return fail(GPT_E_ARG, "gpt_reserve: bad query count");
     if (int rc = set_device(h)) return rc;
     if (M == 0) return GPT_OK;
-    HIPCHK(var_prepare(h->vws, h->stream, h->p, M, jacobian_variance ? 4 : 1));
+    HIPCHK(var_prepare(h->vws, h->stream, h->p, M, jacobian_variance ? var_fused_cols(h->p.D) : 1));
     return GPT_OK;
 }
 
@@ -605,7 +611,9 @@ int gpt_predict_all_dev(gpt_handle* h, const void* Xq, int64_t M, void* mean, vo
         if (prof) HIPCHK(hipEventRecord(h->pev[1], s));
     }
     if (h->pred_var) {
-        const int ncomp = dvar ? 4 : (Jvar ? (var ? 4 : 3) : 1);     // 3: Jacobian variance alone (no k* column)
+        // fused: k* and the D derivative columns of a query side by side; 3: Jacobian variance alone (no k* column, D <= 3)
+        const int fused = var_fused_cols(h->p.D);
+        const int ncomp = dvar ? fused : (Jvar ? ((var || h->p.D > 3) ? fused : 3) : 1);
         HIPCHK(var_prepare(h->vws, s, h->p, M, ncomp));
         if (prof) HIPCHK(hipEventRecord(h->pev[2], s));
         launch_var(s, h->p, h->vws, h->dXs(), h->dWf(), Xq, M, ncomp, var, ncomp == 1 ? nullptr : Jvar, ncomp == 1 ? nullptr : dvar, h->dHdr());
@@ -813,7 +821,7 @@ int gpt_lml_gradient(gpt_handle* h, double* lml, double* grad) {
     const int D = h->p.D, O = h->p.O;
     hipStream_t s = h->stream;
     // K^-1 (lower) into dK, per-tile partial sums into their own scratch
-    const size_t need = (size_t)(NP / 64) * (NP / 64) * 8;
+    const size_t need = (size_t)(NP / 64) * (NP / 64) * LML_PARTIAL_STRIDE;
     if (need > h->lml_partial_cap) {
         HIPCHK(hipStreamSynchronize(s));
         if (h->lml_partial) (void)hipFree(h->lml_partial);
@@ -823,9 +831,9 @@ int gpt_lml_gradient(gpt_handle* h, double* lml, double* grad) {
     }
     h->have_L = false;                                           // L is gone: gpt_export(L) needs a new gpt_fit (W stays valid)
     launch_kinv(s, h->dW, (int)NP, h->dK);
-    launch_lml_terms(s, h->dXs64, h->dA64, h->lay.npass, h->dK, (int)N, (int)NP, O, h->p.ktype, h->p.c, h->lml_partial, h->dscal);
+    launch_lml_terms(s, h->dXs64, D, h->dA64, h->lay.npass, h->dK, (int)N, (int)NP, O, h->p.ktype, h->p.c, h->lml_partial, h->dscal);
     HIPCHK(hipGetLastError());
-    double S[5];
+    double S[LML_TERMS];
     HIPCHK(hipMemcpyAsync(S, h->dscal, sizeof S, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     // theta = log [constant_value, length_scale (1 or D), noise_level]
@@ -837,7 +845,7 @@ int gpt_lml_gradient(gpt_handle* h, double* lml, double* grad) {
     } else {
         for (int d = 0; d < D; ++d) grad[1 + d] = 0.5 * S[1 + d];
     }
-    grad[1 + h->n_ls] = 0.5 * h->p.noise * S[4];
+    grad[1 + h->n_ls] = 0.5 * h->p.noise * S[LML_TERMS - 1];
     return GPT_OK;
 }
 
@@ -851,7 +859,7 @@ int gpt_factor_blob(gpt_handle* h, void** dev_ptr, size_t* bytes) {
 
 int gpt_factor_alloc_model(gpt_handle* h, int64_t N, int D, int O, int n_tasks, int dtype, void** dev_ptr, size_t* bytes) {
     if (!h || !dev_ptr || !bytes) return fail(GPT_E_ARG, "gpt_factor_alloc: NULL argument");
-    if (N < 1 || D < 1 || D > 3 || O < 1 || n_tasks < 1 || n_tasks > MAX_TASKS || (dtype != GPT_F64 && dtype != GPT_F32))
+    if (N < 1 || D < 1 || D > MAX_D || O < 1 || n_tasks < 1 || n_tasks > MAX_TASKS || (dtype != GPT_F64 && dtype != GPT_F32))
         return fail(GPT_E_ARG, "gpt_factor_alloc: bad geometry");
     if (int rc = set_device(h)) return rc;
     h->committed = false;

@@ -30,6 +30,13 @@ constexpr size_t WT_STEP_DOUBLES = (size_t)WT * 4;            // doubles per k4-
 constexpr size_t WT_TILE_DOUBLES = (size_t)WT * WT;           // doubles per tile
 // Cholesky panel width / diagonal block size.
 constexpr int NB = 64;
+// Input dimensions.  D <= 3 (the transport use: planar / spatial positions) is the tuned path: source rows of 4 elements
+// (x, y, z, 0), coordinates in registers.  3 < D <= MAX_D is the wide path: rows of 8, coordinate loops, query
+// coordinates staged through LDS in the variance kernel.
+constexpr int MAX_D = 8;
+inline int xs_stride(int D) { return D <= 3 ? 4 : 8; }
+// Columns per query of the fused variance launch (k*, dk_0 .. dk_{D-1}, zero columns up to a power of two).
+inline int var_fused_cols(int D) { return D <= 3 ? 4 : (D <= 7 ? 8 : 16); }
 
 // Per-device one-time setup (hipFuncSetAttribute opt-ins, CU counts): a process may hold handles on several devices
 // (gpt_create takes a device), so "done once" has to mean once per device, not once per process.
@@ -49,8 +56,8 @@ struct KernelParams {
     double c;            // constant_value (prior variance)
     double lnc;          // log(constant_value)
     double noise;        // WhiteKernel noise_level
-    double inv_ls[3];    // 1/length_scale per input dimension (unused dims: 0)
-    int D;               // input dims (1..3)
+    double inv_ls[MAX_D];   // 1/length_scale per input dimension (unused dims: 0)
+    int D;               // input dims (1..MAX_D)
     int O;               // outputs
     int N;               // source points
     int NP;              // padded source points
@@ -61,7 +68,7 @@ struct KernelParams {
 
 // ---- launchers (defined in the .hip files) --------------------------------------------
 // fit
-void launch_gram(hipStream_t s, const double* Xs, int N, int NP, int ktype, double c, double diag_add, double* K);
+void launch_gram(hipStream_t s, const double* Xs, int D, int N, int NP, int ktype, double c, double diag_add, double* K);
 void launch_add_lower(hipStream_t s, double* K, const double* S, int N, int NP);
 // Streams and events of the overlapped factor + inverse pipeline, owned by a handle: two streams confined to disjoint
 // halves of the CUs (hipExtStreamCreateWithCUMask).  Created on first use; `ok` false = unavailable, everything runs in
@@ -86,8 +93,11 @@ void launch_logdet(hipStream_t s, const double* K, int N, int NP, double* out);
 void launch_kinv(hipStream_t s, const double* W, int NP, double* Kout);
 void launch_cov(hipStream_t s, const KernelParams& p, const double* Xs, const double* W, const double* Xq_dev, int64_t M,
                 int Mp, double* KsT /* NP*Mp */, double* V /* NP*Mp */, double* VtV /* Mp*Mp */, double* cov_dev /* M*M */);
-void launch_lml_terms(hipStream_t s, const double* Xs, const double* A4, int npass, const double* Kinv, int N, int NP,
-                      int O, int ktype, double c, double* partial /* (NP/64)^2*8 doubles */, double* out /* 5 doubles */);
+// out: [d/dlog c, d/dlog l_0 .. l_{MAX_D-1}, d/dlog noise (per unit noise)] = LML_TERMS doubles
+constexpr int LML_TERMS = MAX_D + 2;
+constexpr int LML_PARTIAL_STRIDE = 16;
+void launch_lml_terms(hipStream_t s, const double* Xs, int D, const double* A4, int npass, const double* Kinv, int N, int NP,
+                      int O, int ktype, double c, double* partial /* (NP/64)^2*LML_PARTIAL_STRIDE doubles */, double* out /* LML_TERMS doubles */);
 // predict (buffers in the model's element type)
 void launch_mean_jac(hipStream_t s, const KernelParams& p, const void* Xs, const void* A4,
                      const void* Xq, int64_t M, void* mean, void* J);

@@ -20,34 +20,45 @@ namespace gpt {
 // block lower triangle; padded rows/cols get the identity so the factorisation stays PD.
 // HBM-write bound: one 64x64 tile per workgroup, 16 bytes per lane and store, 8 stores per thread.
 // =====================================================================================
+// DW = 3: rows of 4 (the tuned D <= 3 layout); DW = 8: rows of 8 (3 < D <= 8, unused coordinates are zero).
+template <int DW>
 __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ Xs, int N, int NP, int ktype, double c,
                                               double diag_add, double* __restrict__ K) {
+    constexpr int XS = DW == 3 ? 4 : DW;
     const int bi = blockIdx.y, bj = blockIdx.x;
     if (bj > bi) return;
-    __shared__ double xi[64][3], xj[64][3];
+    __shared__ double xi[64][DW], xj[64][DW];
     const int t = threadIdx.x;
     if (t < 64) {
-        const double* p = Xs + (size_t)(bi * 64 + t) * 4;
-        xi[t][0] = p[0]; xi[t][1] = p[1]; xi[t][2] = p[2];
+        const double* p = Xs + (size_t)(bi * 64 + t) * XS;
+#pragma unroll
+        for (int d = 0; d < DW; ++d) xi[t][d] = p[d];
     } else if (t < 128) {
-        const double* p = Xs + (size_t)(bj * 64 + (t - 64)) * 4;
-        xj[t - 64][0] = p[0]; xj[t - 64][1] = p[1]; xj[t - 64][2] = p[2];
+        const double* p = Xs + (size_t)(bj * 64 + (t - 64)) * XS;
+#pragma unroll
+        for (int d = 0; d < DW; ++d) xj[t - 64][d] = p[d];
     }
     __syncthreads();
     // lane -> column pair, 2 rows per wave-level store: every store instruction writes two contiguous 512-B row segments
     const int cc = (t & 31) * 2;
-    const double b0[2] = {xj[cc][0], xj[cc + 1][0]}, b1[2] = {xj[cc][1], xj[cc + 1][1]}, b2[2] = {xj[cc][2], xj[cc + 1][2]};
+    double b[DW][2];
+#pragma unroll
+    for (int d = 0; d < DW; ++d) { b[d][0] = xj[cc][d]; b[d][1] = xj[cc + 1][d]; }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const int r = (t >> 5) + 8 * u;
         const int i = bi * 64 + r;
-        const double a0 = xi[r][0], a1 = xi[r][1], a2 = xi[r][2];
+        double a[DW];
+#pragma unroll
+        for (int d = 0; d < DW; ++d) a[d] = xi[r][d];
         double v[2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int j = bj * 64 + cc + e;
-            const double d0 = a0 - b0[e], d1 = a1 - b1[e], d2 = a2 - b2[e];
-            double val = kernel_libm(ktype, c, d0 * d0 + d1 * d1 + d2 * d2);
+            double r2 = 0.0;
+#pragma unroll
+            for (int d = 0; d < DW; ++d) { const double df = a[d] - b[d][e]; r2 += df * df; }
+            double val = kernel_libm(ktype, c, r2);
             if (i == j) val = c + diag_add;            // k(0) = 1 exactly (kernels.py:1562)
             if (i >= N || j >= N) val = (i == j) ? 1.0 : 0.0;
             v[e] = val;
@@ -56,9 +67,10 @@ __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ Xs, int
     }
 }
 
-void launch_gram(hipStream_t s, const double* Xs, int N, int NP, int ktype, double c, double diag_add, double* K) {
+void launch_gram(hipStream_t s, const double* Xs, int D, int N, int NP, int ktype, double c, double diag_add, double* K) {
     dim3 grid(NP / 64, NP / 64);
-    hipLaunchKernelGGL(k_gram, grid, dim3(256), 0, s, Xs, N, NP, ktype, c, diag_add, K);
+    if (D <= 3) hipLaunchKernelGGL(k_gram<3>, grid, dim3(256), 0, s, Xs, N, NP, ktype, c, diag_add, K);
+    else hipLaunchKernelGGL(k_gram<MAX_D>, grid, dim3(256), 0, s, Xs, N, NP, ktype, c, diag_add, K);
 }
 
 // K[i][j] += S[i][j] on the lower triangle of the first N rows (S row-major N x N, symmetric): the general
@@ -1055,7 +1067,7 @@ void launch_store4(hipStream_t s, const double* src4, int rows, void* dst4, int 
 // launch_kinv: Kinv = W^T W (lower block triangle, MFMA GEMM) into `Kout`.
 // k_lml_terms: one workgroup per 64x64 lower tile recomputes the RBF part of K from the scaled sources
 // and accumulates  S[0] = sum inner*Krbf (d/dlog c),  S[1+d] = sum inner*Krbf*(xs_id-xs_jd)^2 (d/dlog l_d),
-// S[4] = sum_i inner_ii (d/dlog noise, times noise on the host); off-diagonal elements count twice.
+// and sum_i inner_ii (d/dlog noise, times noise on the host); off-diagonal elements count twice.
 // Per-workgroup partials are summed in a fixed order by k_sum_partials (deterministic).
 // =====================================================================================
 void launch_kinv(hipStream_t s, const double* W, int NP, double* Kout) {
@@ -1066,17 +1078,25 @@ void launch_kinv(hipStream_t s, const double* W, int NP, double* Kout) {
     launch_gemm<false, true>(s, g);
 }
 
+// Partial sums per workgroup: [0] d/dlog c, [1 + d] d/dlog l_d, [1 + DW] the noise term; DW = 3 / MAX_D as in k_gram.
+template <int DW>
 __global__ __launch_bounds__(256) void k_lml_terms(const double* __restrict__ Xs, const double* __restrict__ A4, int npass,
                                                    const double* __restrict__ Kinv, int N, int NP, int O, int ktype, double c,
-                                                   double* __restrict__ partial /* [blocks][8] */) {
+                                                   double* __restrict__ partial /* [blocks][LML_PARTIAL_STRIDE] */) {
+    constexpr int XS = DW == 3 ? 4 : DW;
+    constexpr int NS = DW + 2;
     const int bi = blockIdx.y, bj = blockIdx.x;
     const int t = threadIdx.x;
-    double S[5] = {0, 0, 0, 0, 0};
+    double S[NS];
+#pragma unroll
+    for (int e = 0; e < NS; ++e) S[e] = 0.0;
     if (bj <= bi) {
         const int r = t >> 2, cs = (t & 3) * 16;
         const int i = bi * 64 + r;
         if (i < N) {
-            const double xi0 = Xs[(size_t)i * 4], xi1 = Xs[(size_t)i * 4 + 1], xi2 = Xs[(size_t)i * 4 + 2];
+            double xi[DW];
+#pragma unroll
+            for (int d = 0; d < DW; ++d) xi[d] = Xs[(size_t)i * XS + d];
             for (int u = 0; u < 16; ++u) {
                 const int j = bj * 64 + cs + u;
                 if (j > i || j >= N) continue;
@@ -1088,8 +1108,9 @@ __global__ __launch_bounds__(256) void k_lml_terms(const double* __restrict__ Xs
                 }
                 const double inner = aa - (double)O * Kinv[(size_t)i * NP + j];
                 const double wgt = (i == j) ? 1.0 : 2.0;
-                const double d0 = xi0 - Xs[(size_t)j * 4], d1 = xi1 - Xs[(size_t)j * 4 + 1], d2 = xi2 - Xs[(size_t)j * 4 + 2];
-                const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
+                double df[DW], r2 = 0.0;
+#pragma unroll
+                for (int d = 0; d < DW; ++d) { df[d] = xi[d] - Xs[(size_t)j * XS + d]; r2 += df[d] * df[d]; }
                 const double kr = kernel_libm(ktype, c, r2);
                 // dK/dlog l_d = gk * (xs_id - xs_jd)^2  (kernels.py: RBF 1568-1580, Matern 1747-1778)
                 double gk;
@@ -1103,84 +1124,107 @@ __global__ __launch_bounds__(256) void k_lml_terms(const double* __restrict__ Xs
                 const double wi = wgt * inner;
                 S[0] += wi * kr;
                 const double v = wi * gk;
-                S[1] += v * d0 * d0; S[2] += v * d1 * d1; S[3] += v * d2 * d2;
-                if (i == j) S[4] += inner;
+#pragma unroll
+                for (int d = 0; d < DW; ++d) S[1 + d] += v * df[d] * df[d];
+                if (i == j) S[1 + DW] += inner;
             }
         }
     }
-    __shared__ double red[256][5];
+    __shared__ double red[256][NS];
 #pragma unroll
-    for (int e = 0; e < 5; ++e) red[t][e] = S[e];
+    for (int e = 0; e < NS; ++e) red[t][e] = S[e];
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
         if (t < o)
 #pragma unroll
-            for (int e = 0; e < 5; ++e) red[t][e] += red[t + o][e];
+            for (int e = 0; e < NS; ++e) red[t][e] += red[t + o][e];
         __syncthreads();
     }
-    if (t < 5) partial[((size_t)bi * gridDim.x + bj) * 8 + t] = red[0][t];
+    if (t < NS) partial[((size_t)bi * gridDim.x + bj) * LML_PARTIAL_STRIDE + t] = red[0][t];
 }
 
+// out[0] = d/dlog c, out[1 + d] (d < MAX_D) = d/dlog l_d, out[1 + MAX_D] = the noise term; per-workgroup partials added
+// in a fixed order
+template <int DW>
 __global__ __launch_bounds__(256) void k_sum_partials(const double* __restrict__ partial, int nblocks, double* __restrict__ out) {
-    __shared__ double red[256][5];
-    double S[5] = {0, 0, 0, 0, 0};
+    constexpr int NS = DW + 2;
+    __shared__ double red[256][NS];
+    double S[NS];
+#pragma unroll
+    for (int e = 0; e < NS; ++e) S[e] = 0.0;
     for (int b = threadIdx.x; b < nblocks; b += 256)
 #pragma unroll
-        for (int e = 0; e < 5; ++e) S[e] += partial[(size_t)b * 8 + e];
+        for (int e = 0; e < NS; ++e) S[e] += partial[(size_t)b * LML_PARTIAL_STRIDE + e];
 #pragma unroll
-    for (int e = 0; e < 5; ++e) red[threadIdx.x][e] = S[e];
+    for (int e = 0; e < NS; ++e) red[threadIdx.x][e] = S[e];
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
         if (threadIdx.x < o)
 #pragma unroll
-            for (int e = 0; e < 5; ++e) red[threadIdx.x][e] += red[threadIdx.x + o][e];
+            for (int e = 0; e < NS; ++e) red[threadIdx.x][e] += red[threadIdx.x + o][e];
         __syncthreads();
     }
-    if (threadIdx.x < 5) out[threadIdx.x] = red[0][threadIdx.x];
+    if (threadIdx.x < LML_TERMS) {
+        const int e = threadIdx.x;
+        double v = 0.0;
+        if (e == 0) v = red[0][0];
+        else if (e == LML_TERMS - 1) v = red[0][1 + DW];
+        else if (e - 1 < DW) v = red[0][e];
+        out[e] = v;
+    }
 }
 
-// partial: (NP/64)^2 * 8 doubles of scratch; out: 5 doubles
-void launch_lml_terms(hipStream_t s, const double* Xs, const double* A4, int npass, const double* Kinv, int N, int NP,
+// partial: (NP/64)^2 * LML_PARTIAL_STRIDE doubles of scratch; out: LML_TERMS doubles
+void launch_lml_terms(hipStream_t s, const double* Xs, int D, const double* A4, int npass, const double* Kinv, int N, int NP,
                       int O, int ktype, double c, double* partial, double* out) {
     const int nb = NP / 64;
-    hipLaunchKernelGGL(k_lml_terms, dim3(nb, nb), dim3(256), 0, s, Xs, A4, npass, Kinv, N, NP, O, ktype, c, partial);
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, partial, nb * nb, out);
+    if (D <= 3) {
+        hipLaunchKernelGGL(k_lml_terms<3>, dim3(nb, nb), dim3(256), 0, s, Xs, A4, npass, Kinv, N, NP, O, ktype, c, partial);
+        hipLaunchKernelGGL(k_sum_partials<3>, dim3(1), dim3(256), 0, s, partial, nb * nb, out);
+    } else {
+        hipLaunchKernelGGL(k_lml_terms<MAX_D>, dim3(nb, nb), dim3(256), 0, s, Xs, A4, npass, Kinv, N, NP, O, ktype, c, partial);
+        hipLaunchKernelGGL(k_sum_partials<MAX_D>, dim3(1), dim3(256), 0, s, partial, nb * nb, out);
+    }
 }
 
 // =====================================================================================
 // Posterior covariance  cov = k(Xq,Xq) + noise*I - V^T V,  V = W K*^T  (sklearn/_gpr.py:458-468,
 // where V = L \ K*^T).  Small-M path (sampling, return_cov): K*^T and V are materialised (NP x Mp).
 // =====================================================================================
+struct InvLs { double v[MAX_D]; };
+
 __global__ __launch_bounds__(256) void k_cross_t(const double* __restrict__ Xs, const double* __restrict__ Xq, int N, int NP,
-                                                 int64_t M, int Mp, int D, int ktype, double c, double il0, double il1, double il2,
+                                                 int64_t M, int Mp, int D, int XS, int ktype, double c, InvLs il,
                                                  double* __restrict__ KsT /* [NP][Mp] */) {
     const int t = threadIdx.x;
     const int n = blockIdx.y * 64 + (t >> 2);
     const int m0 = blockIdx.x * 64 + (t & 3) * 16;
-    const double x0 = Xs[(size_t)n * 4], x1 = Xs[(size_t)n * 4 + 1], x2 = Xs[(size_t)n * 4 + 2];
+    double x[MAX_D];
+#pragma unroll
+    for (int d = 0; d < MAX_D; ++d) x[d] = (d < D) ? Xs[(size_t)n * XS + d] : 0.0;
     for (int u = 0; u < 16; ++u) {
         const int m = m0 + u;
         double v = 0.0;
         if (n < N && m < M) {
-            const double q0 = Xq[(size_t)m * D] * il0;
-            const double q1 = D > 1 ? Xq[(size_t)m * D + 1] * il1 : 0.0;
-            const double q2 = D > 2 ? Xq[(size_t)m * D + 2] * il2 : 0.0;
-            const double d0 = x0 - q0, d1 = x1 - q1, d2 = x2 - q2;
-            v = kernel_libm(ktype, c, d0 * d0 + d1 * d1 + d2 * d2);
+            double r2 = 0.0;
+#pragma unroll
+            for (int d = 0; d < MAX_D; ++d)
+                if (d < D) { const double df = x[d] - Xq[(size_t)m * D + d] * il.v[d]; r2 += df * df; }
+            v = kernel_libm(ktype, c, r2);
         }
         KsT[(size_t)n * Mp + m] = v;
     }
 }
 
 __global__ __launch_bounds__(256) void k_cov_finish(const double* __restrict__ Xq, int64_t M, int Mp, int D, int ktype, double c, double noise,
-                                                    double il0, double il1, double il2, const double* __restrict__ VtV,
-                                                    double* __restrict__ cov /* [M][M] */) {
+                                                    InvLs il, const double* __restrict__ VtV, double* __restrict__ cov /* [M][M] */) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= M * M) return;
     const int64_t i = e / M, j = e % M;
     double d2 = 0.0;
-    const double il[3] = {il0, il1, il2};
-    for (int d = 0; d < D; ++d) { const double df = (Xq[i * D + d] - Xq[j * D + d]) * il[d]; d2 += df * df; }
+#pragma unroll
+    for (int d = 0; d < MAX_D; ++d)
+        if (d < D) { const double df = (Xq[i * D + d] - Xq[j * D + d]) * il.v[d]; d2 += df * df; }
     double v = (i == j) ? (c + noise) : kernel_libm(ktype, c, d2);      // k(0) = 1 exactly (kernels.py:1562)
     cov[e] = v - VtV[(size_t)i * Mp + j];
 }
@@ -1189,8 +1233,9 @@ __global__ __launch_bounds__(256) void k_cov_finish(const double* __restrict__ X
 void launch_cov(hipStream_t s, const KernelParams& p, const double* Xs, const double* W, const double* Xq_dev, int64_t M,
                 int Mp, double* KsT, double* V, double* VtV, double* cov_dev) {
     const int NP = p.NP;
-    hipLaunchKernelGGL(k_cross_t, dim3(Mp / 64, NP / 64), dim3(256), 0, s, Xs, Xq_dev, p.N, NP, M, Mp, p.D, p.ktype, p.c,
-                       p.inv_ls[0], p.inv_ls[1], p.inv_ls[2], KsT);
+    InvLs il;
+    for (int d = 0; d < MAX_D; ++d) il.v[d] = p.inv_ls[d];
+    hipLaunchKernelGGL(k_cross_t, dim3(Mp / 64, NP / 64), dim3(256), 0, s, Xs, Xq_dev, p.N, NP, M, Mp, p.D, xs_stride(p.D), p.ktype, p.c, il, KsT);
     GemmArgs a{};
     a.A = W; a.lda = NP; a.B = KsT; a.ldb = Mp; a.C = V; a.ldc = Mp;
     a.M = a.M_last = NP; a.N = Mp; a.K = a.K_last = NP; a.nbatch = 1;
@@ -1203,7 +1248,7 @@ void launch_cov(hipStream_t s, const KernelParams& p, const double* Xs, const do
     launch_gemm<false, true>(s, b);
     const int64_t tot = M * M;
     hipLaunchKernelGGL(k_cov_finish, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, Xq_dev, M, Mp, p.D, p.ktype, p.c, p.noise,
-                       p.inv_ls[0], p.inv_ls[1], p.inv_ls[2], VtV, cov_dev);
+                       il, VtV, cov_dev);
 }
 
 // sum(log(diag(L))) over the first N rows (LML, sklearn/_gpr.py:603).  One workgroup.

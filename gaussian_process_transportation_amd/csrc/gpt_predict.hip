@@ -89,12 +89,14 @@ template <> struct El<float> {
 
 // ------------------------------------------------------------------------------------------
 // OC = outputs handled by this pass (1..4): only their partial sums are accumulated.
-template <typename T, int QPW, int OC, int KT>
+// DW = coordinates carried per point: 3 (source rows of 4: the tuned D <= 3 layout) or MAX_D (rows of 8, D = 4..8).
+template <typename T, int QPW, int OC, int KT, int DW>
 __global__ __launch_bounds__(256) void k_mean_jac(KernelParams p, const T* __restrict__ Xs,
                                                   const T* __restrict__ A4, const T* __restrict__ Xq,
                                                   int64_t M, int o_base, T* __restrict__ mean,
                                                   T* __restrict__ J) {
     typedef typename El<T>::v4 v4;
+    constexpr int XS = DW == 3 ? 4 : DW;            // elements per source row
     __shared__ double Tt[256];
     if (std::is_same<T, double>::value) {
         Tt[threadIdx.x] = g_exp2_table[threadIdx.x];
@@ -105,40 +107,51 @@ __global__ __launch_bounds__(256) void k_mean_jac(KernelParams p, const T* __res
     if (m0 >= M) return;
     const int D = p.D;
     constexpr T RS2 = (T)0.70710678118654752440;    // coordinates scaled by 1/sqrt(2): k = exp(ln c - |d'|^2)
-    T q[QPW][3];
+    T q[QPW][DW];
 #pragma unroll
     for (int i = 0; i < QPW; ++i) {
         const int64_t m = (m0 + i < M) ? (m0 + i) : (M - 1);
 #pragma unroll
-        for (int d = 0; d < 3; ++d) q[i][d] = (d < D) ? Xq[m * D + d] * (T)(p.inv_ls[d] * 0.70710678118654752440) : (T)0;
+        for (int d = 0; d < DW; ++d) q[i][d] = (d < D) ? Xq[m * D + d] * (T)(p.inv_ls[d] * 0.70710678118654752440) : (T)0;
     }
-    T acc[QPW][OC][4];
+    T acc[QPW][OC][1 + DW];
 #pragma unroll
     for (int i = 0; i < QPW; ++i)
 #pragma unroll
         for (int o = 0; o < OC; ++o)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[i][o][e] = (T)0;
+            for (int e = 0; e < 1 + DW; ++e) acc[i][o][e] = (T)0;
 
     const T lnc = (T)p.lnc;
     for (int n = lane; n < p.N; n += 64) {
-        const v4 xs = *reinterpret_cast<const v4*>(Xs + (size_t)n * 4);
+        T x[DW];
+        if constexpr (DW == 3) {
+            const v4 xs = *reinterpret_cast<const v4*>(Xs + (size_t)n * 4);
+            x[0] = xs[0] * RS2; x[1] = xs[1] * RS2; x[2] = xs[2] * RS2;
+        } else {
+#pragma unroll
+            for (int v = 0; v < DW / 4; ++v) {
+                const v4 xs = *reinterpret_cast<const v4*>(Xs + (size_t)n * XS + 4 * v);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[4 * v + e] = xs[e] * RS2;
+            }
+        }
         const v4 al = *reinterpret_cast<const v4*>(A4 + (size_t)n * 4);
-        const T x0 = xs[0] * RS2, x1 = xs[1] * RS2, x2 = xs[2] * RS2;
 #pragma unroll
         for (int i = 0; i < QPW; ++i) {
-            const T d0 = x0 - q[i][0], d1 = x1 - q[i][1], d2 = x2 - q[i][2];
-            T hh = d0 * d0;
-            hh = fma(d1, d1, hh);
-            hh = fma(d2, d2, hh);
+            T df[DW];
+#pragma unroll
+            for (int d = 0; d < DW; ++d) df[d] = x[d] - q[i][d];
+            T hh = df[0] * df[0];
+#pragma unroll
+            for (int d = 1; d < DW; ++d) hh = fma(df[d], df[d], hh);
             const T kv = kernel_tab<KT>(hh, lnc, Tt);
 #pragma unroll
             for (int o = 0; o < OC; ++o) {
                 const T t = kv * al[o];
                 acc[i][o][0] += t;
-                acc[i][o][1] += t * d0;
-                acc[i][o][2] += t * d1;
-                acc[i][o][3] += t * d2;
+#pragma unroll
+                for (int d = 0; d < DW; ++d) acc[i][o][1 + d] += t * df[d];
             }
         }
     }
@@ -147,7 +160,7 @@ __global__ __launch_bounds__(256) void k_mean_jac(KernelParams p, const T* __res
 #pragma unroll
         for (int o = 0; o < OC; ++o)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < 1 + DW; ++e) {
                 T v = acc[i][o][e];
 #pragma unroll
                 for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s);
@@ -166,7 +179,7 @@ __global__ __launch_bounds__(256) void k_mean_jac(KernelParams p, const T* __res
                 if (mean) mean[m * O + oo] = acc[i][o][0];
                 if (J) {
 #pragma unroll
-                    for (int d = 0; d < 3; ++d)
+                    for (int d = 0; d < DW; ++d)
                         if (d < D) J[(m * O + oo) * D + d] = acc[i][o][1 + d] * (T)(p.inv_ls[d] * S2);
                 }
             }
@@ -174,17 +187,17 @@ __global__ __launch_bounds__(256) void k_mean_jac(KernelParams p, const T* __res
     }
 }
 
-template <typename T>
+template <typename T, int DW>
 static void launch_mean_jac_t(hipStream_t s, const KernelParams& p, const T* Xs, const T* A4,
                               const T* Xq, int64_t M, T* mean, T* J) {
-    constexpr int QPW = 2;
+    constexpr int QPW = DW == 3 ? 2 : 1;
     const int64_t waves = (M + QPW - 1) / QPW;
     const int64_t blocks = (waves + 3) / 4;
     for (int ob = 0; ob < p.O; ob += 4) {
         const int cnt = (p.O - ob) < 4 ? (p.O - ob) : 4;
         const T* a4 = A4 + (size_t)(ob / 4) * p.NP * 4;
         const dim3 grid((unsigned)blocks);
-#define GPT_MJ(OC_, KT_) hipLaunchKernelGGL((k_mean_jac<T, QPW, OC_, KT_>), grid, dim3(256), 0, s, p, Xs, a4, Xq, M, ob, mean, J)
+#define GPT_MJ(OC_, KT_) hipLaunchKernelGGL((k_mean_jac<T, QPW, OC_, KT_, DW>), grid, dim3(256), 0, s, p, Xs, a4, Xq, M, ob, mean, J)
 #define GPT_MJ_K(OC_)                                     \
         switch (p.ktype) {                                 \
             case KT_MATERN12: GPT_MJ(OC_, KT_MATERN12); break; \
@@ -206,10 +219,17 @@ static void launch_mean_jac_t(hipStream_t s, const KernelParams& p, const T* Xs,
 void launch_mean_jac(hipStream_t s, const KernelParams& p, const void* Xs, const void* A4,
                      const void* Xq, int64_t M, void* mean, void* J) {
     if (M <= 0 || (!mean && !J)) return;
-    if (p.dtype == DT_F32)
-        launch_mean_jac_t<float>(s, p, (const float*)Xs, (const float*)A4, (const float*)Xq, M, (float*)mean, (float*)J);
-    else
-        launch_mean_jac_t<double>(s, p, (const double*)Xs, (const double*)A4, (const double*)Xq, M, (double*)mean, (double*)J);
+    if (p.D <= 3) {
+        if (p.dtype == DT_F32)
+            launch_mean_jac_t<float, 3>(s, p, (const float*)Xs, (const float*)A4, (const float*)Xq, M, (float*)mean, (float*)J);
+        else
+            launch_mean_jac_t<double, 3>(s, p, (const double*)Xs, (const double*)A4, (const double*)Xq, M, (double*)mean, (double*)J);
+    } else {
+        if (p.dtype == DT_F32)
+            launch_mean_jac_t<float, MAX_D>(s, p, (const float*)Xs, (const float*)A4, (const float*)Xq, M, (float*)mean, (float*)J);
+        else
+            launch_mean_jac_t<double, MAX_D>(s, p, (const double*)Xs, (const double*)A4, (const double*)Xq, M, (double*)mean, (double*)J);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -247,6 +267,10 @@ void launch_mean_jac(hipStream_t s, const KernelParams& p, const void* Xs, const
 // hit rate 97 % -> 56 %, 3.4 TB/s from beyond L2, clock 2.18 GHz), deeper A prefetch (0 %).
 // NCOMP = 1: one column per query (k*).  NCOMP = 4: four columns per query (k*, dk_0, dk_1, dk_2).
 // NCOMP = 3: D columns per query (dk_0 .. dk_{D-1}) — the Jacobian variance without the variance.
+// DW = 3 is all of the above: D <= 3, source rows of 4 elements, query coordinates in registers.  DW = MAX_D is the
+// wide path for D = 4 .. 8 (rows of 8): only the generating sweep differs — the block's query coordinates sit in LDS
+// (qs[d][query]), distances are coordinate loops — with NCOMP = 1, or NCOMP = 8 / 16: k*, dk_0 .. dk_{D-1} and zero
+// columns up to 8 (D <= 7) or 16 per query, so that a query's columns stay inside one 16-column MFMA tile.
 // ------------------------------------------------------------------------------------------
 // Timing-only ablation builds (results are wrong unless 0): -DGPT_ABL=1 no per-chunk barrier, 2 no A-operand
 // loads, 3 diagonal tile skipped, 4 no B fill (LDS image left as is), 5 no MFMAs.  tools/gpu_ablate.sh,
@@ -261,7 +285,7 @@ template <typename T> constexpr size_t var_lds_bytes() {
     return (El<T>::DIAG_LDS && image > chunks) ? image : chunks;
 }
 
-template <typename T, int NCOMP, bool CROSS, int KT>
+template <typename T, int NCOMP, bool CROSS, int KT, int DW = 3>
 __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, const T* __restrict__ Xs,
                                                 const T* __restrict__ Wf, const T* __restrict__ Xq,
                                                 int64_t M, T* __restrict__ slab, T* __restrict__ vslab, T* __restrict__ bscratch) {
@@ -273,8 +297,14 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
     constexpr int VAR_CH = VAR_SUB * VAR_SUBS;          // k4-steps per LDS chunk, one barrier each (32 fp64 / 64 fp32; divides 128)
     extern __shared__ __attribute__((aligned(16))) unsigned char Bs_raw[];       // [buffer][k4-step][lane][column tile]
     T* const Bs_dyn = reinterpret_cast<T*>(Bs_raw);
+    constexpr bool WIDE = DW != 3;
+    constexpr int XS = WIDE ? DW : 4;                   // elements per source row
+    constexpr int CPQ = NCOMP >= 4 ? NCOMP : 1;         // columns per query when they sit side by side (a power of two)
+    static_assert(!WIDE || (DW == 8 && (NCOMP == 1 || NCOMP == 8 || NCOMP == 16)), "wide path: rows of 8, NCOMP 1 / 8 / 16");
+    static_assert(WIDE || NCOMP == 1 || NCOMP == 3 || NCOMP == 4, "D <= 3: NCOMP 1 / 3 / 4");
     __shared__ T red[2][8][VAR_COLS];
     __shared__ double Tt[256];
+    __shared__ T qs[WIDE ? DW : 1][VAR_COLS];           // wide path: scaled coordinates of this block's queries, [d][query]
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lc = lane & 15, lk = lane >> 4;
@@ -287,11 +317,19 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
     // NCOMP=4: column = 4 query + comp, comp = lc & 3 in every tile: b = kv * (cbv + sum_d cd[d] * d'_d).
     // NCOMP=3 (Jacobian variance alone, no k* column): column = D query + d, D columns per query; for D = 3 the d of a
     // lane's column changes from tile to tile and from block to block (16 = 64 = 1 mod 3), selected in `produce`.
-    const int comp = (NCOMP == 4) ? (lc & 3) : 0;
+    const int comp = (CPQ > 1) ? (lc & (CPQ - 1)) : 0;
     const T cbv = (comp == 0) ? (T)1 : (T)0;
     T cd[3];
 #pragma unroll
-    for (int d = 0; d < 3; ++d) cd[d] = (comp == d + 1 && d < D) ? (T)(p.inv_ls[d] * 1.41421356237309504880) : (T)0;
+    for (int d = 0; d < 3; ++d) cd[d] = (!WIDE && comp == d + 1 && d < D) ? (T)(p.inv_ls[d] * 1.41421356237309504880) : (T)0;
+    // wide path: a derivative column needs one coordinate beyond the distance, its own: dimension own_d, factor sc_own
+    // (zero in the k* column and in the zero columns)
+    const int own_d = (WIDE && comp >= 1 && comp <= D) ? comp - 1 : 0;
+    T sc_own = (T)0;
+    if (WIDE) {
+#pragma unroll
+        for (int d = 0; d < DW; ++d) if (comp == d + 1 && d < D) sc_own = (T)(p.inv_ls[d] * 1.41421356237309504880);
+    }
     const T lnc = (T)p.lnc;
     const int nbi = pl.nbi;
     // A stream: element (step S, group g, ...) — uniform base + per-lane 32-bit offset (scalar-base addressing: no
@@ -333,6 +371,17 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
         } else if (flags & VI_GEN) {
             __syncthreads();                               // nobody may still be reading the part of the image rewritten now
         }
+        if (WIDE && (flags & VI_FIRST)) {
+            // the block's queries (64 for NCOMP = 1, 64 / NCOMP otherwise), coordinate w by wave w, scaled as the sources are
+            constexpr int NQ = VAR_COLS / (CPQ > 1 ? CPQ : 1);
+            double il = 0.0;
+#pragma unroll
+            for (int d = 0; d < DW; ++d) if (d == w) il = p.inv_ls[d];
+            const int64_t m = cb * NQ + lane;
+            const int64_t mm = (m < M) ? m : (M - 1);
+            if (lane < NQ) qs[w][lane] = (w < D) ? Xq[mm * D + w] * (T)(il * 0.70710678118654752440) : (T)0;
+            __syncthreads();
+        }
         if (flags & VI_ZERO) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) { ssq[t] = (T)0; crs[t] = (T)0; }
@@ -348,7 +397,7 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
             constexpr bool GEN = decltype(gen_tag)::value;
             // this lane's four columns (one per MFMA column tile): scaled query coordinates
             T q[4][3];
-            if (GEN) {
+            if (GEN && !WIDE) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const int64_t col = cb * VAR_COLS + 16 * t + lc;
@@ -358,19 +407,47 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
                     for (int d = 0; d < 3; ++d) q[t][d] = (d < D) ? Xq[mm * D + d] * (T)(p.inv_ls[d] * 0.70710678118654752440) : (T)0;
                 }
             }
-            T gx[3];                                       // coordinates of the source this wave generates next
+            T gx[DW];                                      // coordinates of the source this wave generates next
+            T gx_own = (T)0;                               // (wide) and the one a derivative column multiplies by
             v4 bl;                                         // or the fragments it reloads next
-            auto fetch = [&](const int k4) {
-                if (GEN) {
-                    const T* xp = Xs + (size_t)(k4 * 4 + lk) * 4;
-                    gx[0] = xp[0]; gx[1] = xp[1]; gx[2] = xp[2];
+            auto load_x = [&](const T* xp) {
+                if constexpr (WIDE) {
+#pragma unroll
+                    for (int v = 0; v < DW / 4; ++v) {
+                        const v4 xv = *reinterpret_cast<const v4*>(xp + 4 * v);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) gx[4 * v + e] = xv[e];
+                    }
+                    if (NCOMP != 1) gx_own = xp[own_d];
                 } else {
-                    bl = (buni + (size_t)k4 * 64)[lane];
+                    gx[0] = xp[0]; gx[1] = xp[1]; gx[2] = xp[2];
                 }
+            };
+            auto fetch = [&](const int k4) {
+                if (GEN) load_x(Xs + (size_t)(k4 * 4 + lk) * XS);
+                else bl = (buni + (size_t)k4 * 64)[lane];
             };
             auto produce = [&](const int buf, const int k4) {   // B fragments of k-step k4 -> LDS (+ scratch)
                 T* dstl = Bs(buf, k4 % VAR_CH);
-                if (GEN) {
+                if constexpr (GEN && WIDE) {
+                    T x[DW];
+#pragma unroll
+                    for (int d = 0; d < DW; ++d) x[d] = gx[d] * RS2;
+                    const T xo = gx_own * RS2;
+                    v4 b;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int qi = (16 * t + lc) / (CPQ > 1 ? CPQ : 1);      // this column's query within the block
+                        T df = x[0] - qs[0][qi];
+                        T hh = df * df;
+#pragma unroll
+                        for (int d = 1; d < DW; ++d) { df = x[d] - qs[d][qi]; hh = fma(df, df, hh); }
+                        const T kv = kernel_tab<KT>(hh, lnc, Tt);
+                        b[t] = (NCOMP == 1) ? kv : kv * (cbv + sc_own * (xo - qs[own_d][qi]));
+                    }
+                    *reinterpret_cast<v4*>(dstl) = b;
+                    (buni + (size_t)k4 * 64)[lane] = b;
+                } else if (GEN) {
                     const T x0 = gx[0] * RS2, x1 = gx[1] * RS2, x2 = gx[2] * RS2;
                     v4 b;
 #pragma unroll
@@ -437,11 +514,11 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
             // the previous fill's destination registers — and that write-after-load made hipcc drain vmcnt to 0 (and with
             // it the A fragments in flight) at the top of every sub-chunk.
             const v4* bsrc = buni + (size_t)(K0 + VAR_CH + w) * 64 + lane;
-            const T* xsrc = Xs + (size_t)((K0 + VAR_CH + w) * 4 + lk) * 4;
+            const T* xsrc = Xs + (size_t)((K0 + VAR_CH + w) * 4 + lk) * XS;
             auto fetch_next = [&]() {
                 if (GEN) {
-                    gx[0] = xsrc[0]; gx[1] = xsrc[1]; gx[2] = xsrc[2];
-                    xsrc += VAR_SUB * 16;
+                    load_x(xsrc);
+                    xsrc += VAR_SUB * 4 * XS;
                 } else {
                     bl = bsrc[0];
                     bsrc += VAR_SUB * 64;
@@ -575,7 +652,7 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
                         for (int e = 0; e < 4; ++e) {
                             const T v = acc[r][t][e];
                             ssq[t] += v * v;
-                            if (CROSS) crs[t] += v * __shfl(v, lane & ~3);
+                            if (CROSS) crs[t] += v * __shfl(v, lane & ~(CPQ - 1));
                         }
             }
         };
@@ -619,7 +696,7 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
 
 // A sweep the work split cut along k: add its parts' partial products in part order, then square / reduce as the
 // kernel's own epilogue does.  One workgroup per cut sweep, same thread -> element map as k_var.
-template <typename T, bool CROSS>
+template <typename T, bool CROSS, int CPQ = 4>
 __global__ __launch_bounds__(512) void k_var_combine(VarPlanDev pl, const T* __restrict__ vslab, T* __restrict__ slab) {
     typedef typename El<T>::v4 v4;
     __shared__ T red[2][8][VAR_COLS];
@@ -643,7 +720,7 @@ __global__ __launch_bounds__(512) void k_var_combine(VarPlanDev pl, const T* __r
             for (int e = 0; e < 4; ++e) {
                 const T v = acc[r * 4 + t][e];
                 ssq[t] += v * v;
-                if (CROSS) crs[t] += v * __shfl(v, lane & ~3);
+                if (CROSS) crs[t] += v * __shfl(v, lane & ~(CPQ - 1));
             }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -677,8 +754,8 @@ __global__ __launch_bounds__(64) void k_var_finalize(KernelParams p, VarPlanDev 
     const int cl = threadIdx.x;
     const int D = p.D, NT = pl.ntask;
     const int64_t col = cb * VAR_COLS + cl;
-    const int64_t m = (NCOMP == 1) ? col : ((NCOMP == 4) ? (col >> 2) : (col / D));
-    const int cmp = (NCOMP == 1) ? 0 : ((NCOMP == 4) ? (int)(col & 3) : 1 + (int)(col % D));
+    const int64_t m = (NCOMP == 1) ? col : ((NCOMP >= 4) ? (col / NCOMP) : (col / D));
+    const int cmp = (NCOMP == 1) ? 0 : ((NCOMP >= 4) ? (int)(col & (NCOMP - 1)) : 1 + (int)(col % D));
     for (int task = 0; task < NT; ++task) {
         T s2 = (T)0, cr = (T)0;
         int s_begin, s_end;
@@ -714,7 +791,12 @@ static void var_kernel_setup() {
     const void* fns[] = {reinterpret_cast<const void*>(k_var<T, 1, false, KT_RBF>), reinterpret_cast<const void*>(k_var<T, 4, true, KT_RBF>),
                          reinterpret_cast<const void*>(k_var<T, 4, false, KT_RBF>), reinterpret_cast<const void*>(k_var<T, 3, false, KT_RBF>),
                          reinterpret_cast<const void*>(k_var<T, 1, false, KT_MATERN12>),
-                         reinterpret_cast<const void*>(k_var<T, 1, false, KT_MATERN32>), reinterpret_cast<const void*>(k_var<T, 1, false, KT_MATERN52>)};
+                         reinterpret_cast<const void*>(k_var<T, 1, false, KT_MATERN32>), reinterpret_cast<const void*>(k_var<T, 1, false, KT_MATERN52>),
+                         // D = 4 .. 8
+                         reinterpret_cast<const void*>(k_var<T, 1, false, KT_RBF, MAX_D>), reinterpret_cast<const void*>(k_var<T, 1, false, KT_MATERN12, MAX_D>),
+                         reinterpret_cast<const void*>(k_var<T, 1, false, KT_MATERN32, MAX_D>), reinterpret_cast<const void*>(k_var<T, 1, false, KT_MATERN52, MAX_D>),
+                         reinterpret_cast<const void*>(k_var<T, 8, true, KT_RBF, MAX_D>), reinterpret_cast<const void*>(k_var<T, 8, false, KT_RBF, MAX_D>),
+                         reinterpret_cast<const void*>(k_var<T, 16, true, KT_RBF, MAX_D>), reinterpret_cast<const void*>(k_var<T, 16, false, KT_RBF, MAX_D>)};
     for (const void* f : fns) hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)var_lds_bytes<T>());
 }
 
@@ -728,30 +810,45 @@ static void launch_var_t(hipStream_t s, const KernelParams& p, const VarWorkspac
     T* vslab = static_cast<T*>(ws.vslab);
     T* bscr = static_cast<T*>(ws.bscratch);
     const dim3 grid((unsigned)pl.P), fgrid((unsigned)pl.ncb), cgrid((unsigned)pl.n_splits);
-#define GPT_KVAR(NC_, CR_, KT_) hipLaunchKernelGGL((k_var<T, NC_, CR_, KT_>), grid, dim3(512), lds, s, p, pl, Xs, Wf, Xq, M, slab, vslab, bscr)
-    bool cross = false;
-    if (ncomp == 1) {
-        switch (p.ktype) {
-            case KT_MATERN12: GPT_KVAR(1, false, KT_MATERN12); break;
-            case KT_MATERN32: GPT_KVAR(1, false, KT_MATERN32); break;
-            case KT_MATERN52: GPT_KVAR(1, false, KT_MATERN52); break;
-            default: GPT_KVAR(1, false, KT_RBF);
+    const bool wide = p.D > 3;
+#define GPT_KVAR(NC_, CR_, KT_, DW_) hipLaunchKernelGGL((k_var<T, NC_, CR_, KT_, DW_>), grid, dim3(512), lds, s, p, pl, Xs, Wf, Xq, M, slab, vslab, bscr)
+#define GPT_KVAR1(DW_)                                                  \
+        switch (p.ktype) {                                               \
+            case KT_MATERN12: GPT_KVAR(1, false, KT_MATERN12, DW_); break; \
+            case KT_MATERN32: GPT_KVAR(1, false, KT_MATERN32, DW_); break; \
+            case KT_MATERN52: GPT_KVAR(1, false, KT_MATERN52, DW_); break; \
+            default: GPT_KVAR(1, false, KT_RBF, DW_);                    \
         }
-    } else if (ncomp == 3) {      // Jacobian variance alone: D columns per query
-        GPT_KVAR(3, false, KT_RBF);
-    } else {                      // Jacobian variance / d var: RBF only (the API refuses other kernels)
-        cross = dvar != nullptr;
-        if (cross) GPT_KVAR(4, true, KT_RBF);
-        else GPT_KVAR(4, false, KT_RBF);
+    const bool cross = ncomp >= 4 && dvar != nullptr;
+    if (ncomp == 1) {
+        if (wide) { GPT_KVAR1(MAX_D) } else { GPT_KVAR1(3) }
+    } else if (ncomp == 3) {      // Jacobian variance alone: D columns per query (D <= 3)
+        GPT_KVAR(3, false, KT_RBF, 3);
+    } else if (ncomp == 4) {      // Jacobian variance / d var: RBF only (the API refuses other kernels)
+        if (cross) GPT_KVAR(4, true, KT_RBF, 3);
+        else GPT_KVAR(4, false, KT_RBF, 3);
+    } else if (ncomp == 8) {      // D = 4 .. 7
+        if (cross) GPT_KVAR(8, true, KT_RBF, MAX_D);
+        else GPT_KVAR(8, false, KT_RBF, MAX_D);
+    } else {                      // D = 8
+        if (cross) GPT_KVAR(16, true, KT_RBF, MAX_D);
+        else GPT_KVAR(16, false, KT_RBF, MAX_D);
     }
+#undef GPT_KVAR1
 #undef GPT_KVAR
     if (pl.n_splits > 0) {
-        if (cross) hipLaunchKernelGGL((k_var_combine<T, true>), cgrid, dim3(512), 0, s, pl, vslab, slab);
-        else hipLaunchKernelGGL((k_var_combine<T, false>), cgrid, dim3(512), 0, s, pl, vslab, slab);
+        if (!cross) hipLaunchKernelGGL((k_var_combine<T, false>), cgrid, dim3(512), 0, s, pl, vslab, slab);
+        else if (ncomp == 4) hipLaunchKernelGGL((k_var_combine<T, true, 4>), cgrid, dim3(512), 0, s, pl, vslab, slab);
+        else if (ncomp == 8) hipLaunchKernelGGL((k_var_combine<T, true, 8>), cgrid, dim3(512), 0, s, pl, vslab, slab);
+        else hipLaunchKernelGGL((k_var_combine<T, true, 16>), cgrid, dim3(512), 0, s, pl, vslab, slab);
     }
-    if (ncomp == 1) hipLaunchKernelGGL((k_var_finalize<T, 1>), fgrid, dim3(64), 0, s, p, pl, slab, M, hdr, var, Jvar, dvar);
-    else if (ncomp == 3) hipLaunchKernelGGL((k_var_finalize<T, 3>), fgrid, dim3(64), 0, s, p, pl, slab, M, hdr, var, Jvar, dvar);
-    else hipLaunchKernelGGL((k_var_finalize<T, 4>), fgrid, dim3(64), 0, s, p, pl, slab, M, hdr, var, Jvar, dvar);
+    switch (ncomp) {
+        case 1: hipLaunchKernelGGL((k_var_finalize<T, 1>), fgrid, dim3(64), 0, s, p, pl, slab, M, hdr, var, Jvar, dvar); break;
+        case 3: hipLaunchKernelGGL((k_var_finalize<T, 3>), fgrid, dim3(64), 0, s, p, pl, slab, M, hdr, var, Jvar, dvar); break;
+        case 4: hipLaunchKernelGGL((k_var_finalize<T, 4>), fgrid, dim3(64), 0, s, p, pl, slab, M, hdr, var, Jvar, dvar); break;
+        case 8: hipLaunchKernelGGL((k_var_finalize<T, 8>), fgrid, dim3(64), 0, s, p, pl, slab, M, hdr, var, Jvar, dvar); break;
+        default: hipLaunchKernelGGL((k_var_finalize<T, 16>), fgrid, dim3(64), 0, s, p, pl, slab, M, hdr, var, Jvar, dvar);
+    }
 }
 
 void launch_var(hipStream_t s, const KernelParams& p, const VarWorkspace& ws, const void* Xs, const void* Wf,

@@ -18,8 +18,8 @@ static void touch_r(const void* p, size_t bytes) {
 size_t wf_elems(int NP) { const size_t nb = NP / WT; return nb * (nb + 1) / 2 * WT_TILE_DOUBLES; }
 size_t wf_overrun_elems() { return WT_STEP_DOUBLES; }
 
-void launch_gram(hipStream_t, const double* Xs, int, int NP, int, double, double, double* K) {
-    touch_r(Xs, (size_t)NP * 4 * 8); touch_w(K, (size_t)NP * NP * 8);
+void launch_gram(hipStream_t, const double* Xs, int D, int, int NP, int, double, double, double* K) {
+    touch_r(Xs, (size_t)NP * xs_stride(D) * 8); touch_w(K, (size_t)NP * NP * 8);
 }
 void launch_add_lower(hipStream_t, double* K, const double* S, int N, int NP) { touch_r(S, (size_t)N * N * 8); touch_w(K, (size_t)NP * NP * 8); }
 void fit_aux_release(FitAux&) {}
@@ -42,17 +42,17 @@ void launch_logdet(hipStream_t, const double* K, int, int NP, double* out) { tou
 void launch_kinv(hipStream_t, const double* W, int NP, double* Kout) { touch_r(W, (size_t)NP * NP * 8); touch_w(Kout, (size_t)NP * NP * 8); }
 void launch_cov(hipStream_t, const KernelParams& p, const double* Xs, const double* W, const double* Xq, int64_t M, int Mp, double* KsT,
                 double* V, double* VtV, double* cov) {
-    touch_r(Xs, (size_t)p.NP * 32); touch_r(W, (size_t)p.NP * p.NP * 8); touch_r(Xq, (size_t)M * p.D * 8);
+    touch_r(Xs, (size_t)p.NP * xs_stride(p.D) * 8); touch_r(W, (size_t)p.NP * p.NP * 8); touch_r(Xq, (size_t)M * p.D * 8);
     touch_w(KsT, (size_t)p.NP * Mp * 8); touch_w(V, (size_t)p.NP * Mp * 8); touch_w(VtV, (size_t)Mp * Mp * 8); touch_w(cov, (size_t)M * M * 8);
 }
-void launch_lml_terms(hipStream_t, const double* Xs, const double* A4, int npass, const double* Kinv, int, int NP, int, int, double,
+void launch_lml_terms(hipStream_t, const double* Xs, int D, const double* A4, int npass, const double* Kinv, int, int NP, int, int, double,
                       double* partial, double* out) {
-    touch_r(Xs, (size_t)NP * 32); touch_r(A4, (size_t)npass * NP * 32); touch_r(Kinv, (size_t)NP * NP * 8);
-    touch_w(partial, (size_t)(NP / 64) * (NP / 64) * 64); touch_w(out, 5 * 8);
+    touch_r(Xs, (size_t)NP * xs_stride(D) * 8); touch_r(A4, (size_t)npass * NP * 32); touch_r(Kinv, (size_t)NP * NP * 8);
+    touch_w(partial, (size_t)(NP / 64) * (NP / 64) * LML_PARTIAL_STRIDE * 8); touch_w(out, LML_TERMS * 8);
 }
 void launch_mean_jac(hipStream_t, const KernelParams& p, const void* Xs, const void* A4, const void* Xq, int64_t M, void* mean, void* J) {
     const size_t e = esz(p.dtype);
-    touch_r(Xs, (size_t)p.NP * 4 * e); touch_r(A4, (size_t)((p.O + 3) / 4) * p.NP * 4 * e); touch_r(Xq, (size_t)M * p.D * e);
+    touch_r(Xs, (size_t)p.NP * xs_stride(p.D) * e); touch_r(A4, (size_t)((p.O + 3) / 4) * p.NP * 4 * e); touch_r(Xq, (size_t)M * p.D * e);
     touch_w(mean, (size_t)M * p.O * e); touch_w(J, (size_t)M * p.O * p.D * e);
 }
 void launch_var(hipStream_t, const KernelParams& p, const VarWorkspace& ws, const void* Xs, const void* Wf, const void* Xq, int64_t M,
@@ -60,7 +60,7 @@ void launch_var(hipStream_t, const KernelParams& p, const VarWorkspace& ws, cons
     if (M <= 0 || !ws.plan) return;
     const size_t e = esz(p.dtype);
     const VarPlanHost& pl = *ws.plan;
-    touch_r(Xs, (size_t)p.NP * 4 * e); touch_r(Xq, (size_t)M * p.D * e); touch_r(hdr, (16 + p.ntask) * 8);
+    touch_r(Xs, (size_t)p.NP * xs_stride(p.D) * e); touch_r(Xq, (size_t)M * p.D * e); touch_r(hdr, (16 + p.ntask) * 8);
     touch_r(Wf, ((size_t)p.ntask * wf_elems(p.NP) + wf_overrun_elems()) * e);
     unsigned char* base = static_cast<unsigned char*>(ws.plan_dev);                   // the uploaded image, as the kernels index it
     const int* item_begin = pl.d.item_begin;

@@ -23,13 +23,20 @@ for bad in (lambda: _lib.Handle(3), lambda: h.predict_all(np.zeros((2, 3)), mean
         continue
     raise AssertionError("an invalid call went through")
 
-for N, D, O in ((1, 1, 1), (700, 3, 3), (1100, 2, 6)):
+for bad in (lambda: h.fit(np.zeros((3, 9)), np.zeros((3, 2)), [1.0], 1.0, 0.1, 0.0),):        # D beyond MAX_D
+    try:
+        bad()
+    except ValueError:
+        continue
+    raise AssertionError("D = 9 went through")
+
+for N, D, O in ((1, 1, 1), (700, 3, 3), (1100, 2, 6), (530, 5, 5), (200, 8, 2), (64, 4, 1)):
     X = rng.uniform(0, 1, (N, D)); Y = rng.standard_normal((N, O))
     for dtype in (_lib.GPT_F64, _lib.GPT_F32):
         h.set_dtype(dtype)
         h.fit(X, Y, np.full(D, 0.3), 1.0, 1e-2, 1e-10)
         assert h.model_info() == (1, dtype) and h.info()[:3] == (N, D, O)
-        for M in (1, 63, 460, 4097, 140_000):
+        for M in (1, 63, 460, 4097, 140_000 if D <= 3 else 20_000):
             q = rng.uniform(0, 1, (M, D))
             out = h.predict_all(q, mean=True, var=True, J=True, Jvar=True, dvar=True)
             assert out["mean"].shape == (M, O) and out["dvar"].shape == (D, M)

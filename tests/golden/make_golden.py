@@ -78,8 +78,8 @@ def gp_outputs(gp, Xq, with_L=True, with_cov=0, with_jvar=True):
 
 
 def case_synthetic(pt, N, M, name, ls=(0.1, 0.1, 0.1), nan_rows=(), with_L=True, with_cov=0,
-                   with_jvar=True, lml=True):
-    X, Y, Xq = synthetic(N, M)
+                   with_jvar=True, lml=True, D=3):
+    X, Y, Xq = synthetic(N, M, D=D)
     Y = Y.copy()
     for r in nan_rows:
         Y[r, r % 3] = np.nan
@@ -276,7 +276,7 @@ def case_n8192(pt):
 def main(argv):
     warnings.filterwarnings("ignore")
     pt, resample = import_reference()
-    cases = argv or ["n64", "n64iso", "n64nan", "n256", "n1024", "letterS", "matern"]
+    cases = argv or ["n64", "n64iso", "n64nan", "n256", "n1024", "n200d5", "n128d8", "letterS", "matern"]
     for c in cases:
         if c == "n64":
             case_synthetic(pt, 64, 48, "synthetic_3d_N64", with_cov=16)
@@ -288,6 +288,10 @@ def main(argv):
             case_synthetic(pt, 256, 96, "synthetic_3d_N256")
         elif c == "n1024":
             case_synthetic(pt, 1024, 128, "synthetic_3d_N1024", with_L=False)
+        elif c == "n200d5":     # input dimension beyond 3: the wide layout of the HIP path (ARD length-scales, 5 outputs)
+            case_synthetic(pt, 200, 80, "synthetic_5d_N200", ls=(0.3, 0.5, 0.4, 0.6, 0.35), with_cov=12, D=5)
+        elif c == "n128d8":
+            case_synthetic(pt, 128, 40, "synthetic_8d_N128", ls=(0.7,), with_cov=8, D=8)
         elif c == "letterS":
             case_letterS(pt, resample)
         elif c == "matern":

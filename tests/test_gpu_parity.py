@@ -27,7 +27,8 @@ def fitted_gp(g):
     return gp
 
 
-SYN = ["synthetic_3d_N64", "synthetic_3d_N64_iso", "synthetic_3d_N64_nan", "synthetic_3d_N256", "synthetic_3d_N1024"]
+SYN = ["synthetic_3d_N64", "synthetic_3d_N64_iso", "synthetic_3d_N64_nan", "synthetic_3d_N256", "synthetic_3d_N1024",
+       "synthetic_5d_N200", "synthetic_8d_N128"]          # the last two: input dimension beyond 3 (the wide layout)
 
 
 @pytest.mark.parametrize("name", SYN)
@@ -198,6 +199,110 @@ def test_ragged_shapes_vs_oracle(N, M, D, O, ls):
     h.close()
 
 
+@pytest.mark.parametrize("N,M,D,O,ls", [(5, 3, 4, 1, (0.5,)), (257, 300, 4, 5, (0.4, 0.6, 0.5, 0.3)), (700, 5000, 6, 2, (0.6,)),
+                                        (1300, 460, 7, 3, (0.5, 0.7, 0.6, 0.8, 0.5, 0.9, 0.6)), (600, 1031, 8, 1, (0.8,)),
+                                        (1100, 70, 5, 6, (0.3, 0.5, 0.4, 0.6, 0.35))])
+def test_input_dimension_beyond_three_vs_oracle(N, M, D, O, ls):
+    """The reference regressor takes any input dimension (models/gaussian_process.py:63-102 builds (D,M,N) operands for
+    any D); here D = 4 .. 8 run on the wide layout (source rows of 8, 8 / 16 columns per query in the fused variance
+    launch).  Sizes off the tile boundaries, few queries (cut sweeps) and many (whole rounds), isotropic and ARD."""
+    from gaussian_process_transportation_amd import _lib
+    from oracle import gp_oracle as orc
+    rng = np.random.default_rng(N + M + D)
+    X = rng.uniform(0, 1, (N, D))
+    Y = 0.05 * np.sin(4 * X[:, :1] + np.arange(O)[None, :]) + 0.01 * rng.standard_normal((N, O))
+    Xq = rng.uniform(-0.1, 1.1, (M, D))
+    c, noise, jit = 0.1, 1e-4, 1e-10
+    h = _lib.Handle(0)
+    h.fit(X, Y, np.asarray(ls), c, noise, jit)
+    o = orc.GaussianProcessOracle(c, np.asarray(ls), noise, jit).fit(X, Y)
+    L, a = h.export()
+    assert_parity(L, o.L_, RTOL, "L")
+    assert_parity(a, o.alpha_, RTOL, "alpha")
+    out = h.predict_all(Xq, mean=True, var=True, J=True, Jvar=True, dvar=True)
+    sub = np.sort(rng.choice(M, min(M, 600), replace=False))          # the CPU oracle checks a subset of a large batch
+    mean, std = o.predict(Xq[sub], return_std=True)
+    std = std if std.ndim == 1 else std[:, 0]
+    J, Jv = o.derivative(Xq[sub], return_var=True)
+    assert_parity(out["mean"][sub], np.reshape(mean, (len(sub), O)), RTOL, "mean")
+    assert_parity(out["var"][sub], (std + np.sqrt(noise)) ** 2, RTOL, "var")
+    assert_parity(out["J"][sub], J, RTOL, "J")
+    assert_parity(out["Jvar"][sub], Jv[:, 0, :], RTOL, "Jvar")
+    assert_parity(out["dvar"][:, sub], o.derivative_of_variance(Xq[sub]), RTOL, "dvar")
+    assert_parity(h.predict_all(Xq, var=True)["var"], out["var"], 1e-12, "var (1-column kernel) vs var (fused kernel)")
+    assert_parity(h.predict_all(Xq, Jvar=True)["Jvar"], out["Jvar"], 1e-12, "Jvar alone vs fused")
+    # the same model in fp32: against the fp64 result, at fp32's resolution of the prior scales
+    h.set_dtype(_lib.GPT_F32)
+    h.fit(X, Y, np.asarray(ls), c, noise, jit)
+    o32 = h.predict_all(Xq, mean=True, var=True, J=True, Jvar=True)
+    assert o32["var"].dtype == np.float32
+    ils2 = float(np.max(1.0 / np.broadcast_to(np.asarray(ls), (D,)) ** 2))
+    assert np.max(np.abs(o32["var"] - out["var"])) < 2e-4 * c
+    assert np.max(np.abs(o32["Jvar"] - out["Jvar"])) < 2e-4 * c * ils2
+    h.close()
+
+
+def test_gaussian_process_class_in_six_dimensions_matches_sklearn_after_optimisation():
+    """GaussianProcess (the reference's class surface) on a 6-D input with the optimizer on: the fitted hyper-parameters
+    and the log-marginal likelihood against scikit-learn's own GaussianProcessRegressor run from the same start with the
+    same global-RNG restarts (sklearn/_gpr.py:248-330), the predictions against sklearn's at the fitted kernel."""
+    from sklearn.gaussian_process import GaussianProcessRegressor
+    from gaussian_process_transportation_amd import GaussianProcess
+    rng = np.random.default_rng(11)
+    N, D = 300, 6
+    X = rng.uniform(0, 1, (N, D))
+    Y = np.column_stack([np.sin(3 * X[:, 0]) * X[:, 3], np.cos(2 * X[:, 1] + X[:, 5])]) + 0.02 * rng.standard_normal((N, 2))
+    k0 = sk_kernel(1.0, 0.7 * np.ones(D), 0.01)
+    np.random.seed(3)
+    ref = GaussianProcessRegressor(kernel=k0, alpha=1e-10, n_restarts_optimizer=2).fit(X, Y)
+    np.random.seed(3)
+    gp = GaussianProcess(kernel=k0, alpha=1e-10, n_restarts_optimizer=2, verbose=False).fit(X, Y)
+    assert gp.gp.log_marginal_likelihood_value_ == pytest.approx(ref.log_marginal_likelihood_value_, rel=1e-6)
+    assert_parity(gp.gp.kernel_.theta, ref.kernel_.theta, 1e-3, "fitted theta")
+    Xq = rng.uniform(0, 1, (500, D))
+    fixed = GaussianProcess(kernel=ref.kernel_, alpha=1e-10, optimizer=None, verbose=False).fit(X, Y)
+    m_ref, s_ref = ref.predict(Xq, return_std=True)
+    m, s = fixed.predict(Xq, return_std=True)
+    assert_parity(m, m_ref, RTOL, "mean at sklearn's fitted kernel")
+    noise = float(np.exp(ref.kernel_.theta[-1]))
+    # the reference class reports sqrt(var without noise) (gaussian_process.py:57-58); sklearn's std includes the WhiteKernel
+    assert_parity((s[:, 0] + np.sqrt(noise)) ** 2, s_ref[:, 0] ** 2, RTOL, "variance at sklearn's fitted kernel")
+
+
+def test_svgp_exact_conversion_in_six_dimensions():
+    """The multi-task SVGP exact-conversion model on a 6-D input (wide layout), fp64 against the CPU restatement and fp32
+    within what the same algebra loses in numpy float32."""
+    from gaussian_process_transportation_amd import _lib
+    from oracle import gp_oracle as orc
+    rng = np.random.default_rng(5)
+    Z, T, D, M = 700, 3, 6, 2500
+    Zp = rng.uniform(0, 1, (Z, D))
+    A = rng.standard_normal((T, Z, Z))
+    Sigma = A @ A.transpose(0, 2, 1) / Z * 0.05 + 1e-3 * np.eye(Z)
+    y = rng.standard_normal((T, Z))
+    osc = np.array([0.7, 1.3, 2.0])
+    ls = np.array([0.5, 0.7, 0.6, 0.9, 0.55, 0.8])
+    Xq = rng.uniform(-0.1, 1.1, (M, D))
+    rm, rs, rJ, rJs = orc.svgp_exact_oracle_fast(Xq, Zp, Sigma, y, osc, ls)
+    h = _lib.Handle(0)
+    h.fit_svgp(Zp, y, Sigma, ls, osc, dtype=_lib.GPT_F64)
+    out = h.predict_all(Xq, mean=True, var=True, J=True, Jvar=True)
+    assert_parity(out["mean"], rm, 1e-7, "mean")
+    assert_parity(out["var"], rs ** 2, 1e-7, "var")
+    assert_parity(out["J"], rJ, 1e-7, "J")
+    assert_parity(out["Jvar"], rJs ** 2, 1e-7, "Jvar")
+    m32, s32, J32, Js32 = orc.svgp_exact_oracle_fast(Xq, Zp, Sigma, y, osc, ls, dtype=np.float32)
+    h.fit_svgp(Zp, y, Sigma, ls, osc, dtype=_lib.GPT_F32)
+    o32 = h.predict_all(Xq, mean=True, var=True, J=True, Jvar=True)
+    vs, js = float(np.max(osc)), float(np.max(osc[:, None] / ls[None, :] ** 2))
+    for name, got, want, ref32, scale in (("var", o32["var"], rs ** 2, s32.astype(float) ** 2, vs),
+                                          ("Jvar", o32["Jvar"], rJs ** 2, Js32.astype(float) ** 2, js)):
+        err = float(np.max(np.abs(got - want))) / scale
+        lim = max(2e-4, 2 * float(np.max(np.abs(ref32 - want))) / scale)
+        assert err <= lim, f"fp32 {name}: {err:.2e} > {lim:.2e}"
+    h.close()
+
+
 def test_empty_query_and_errors():
     from gaussian_process_transportation_amd import _lib, GaussianProcess
     h = _lib.Handle(0)
@@ -341,7 +446,8 @@ def test_full_size_properties():
     h.close()
 
 
-@pytest.mark.parametrize("name", ["synthetic_3d_N64", "synthetic_3d_N64_iso", "synthetic_3d_N256", "synthetic_3d_N1024"])
+@pytest.mark.parametrize("name", ["synthetic_3d_N64", "synthetic_3d_N64_iso", "synthetic_3d_N256", "synthetic_3d_N1024",
+                                  "synthetic_5d_N200", "synthetic_8d_N128"])
 def test_lml_value_and_gradient_vs_sklearn(name):
     """gpt_lml_gradient against sklearn's log_marginal_likelihood(theta, eval_gradient=True) at three thetas."""
     from gaussian_process_transportation_amd import _lib
@@ -821,7 +927,7 @@ def test_non_finite_inputs_raise_like_sklearn():
             call()
     h = _lib.Handle(0)
     with pytest.raises(ValueError):
-        h.fit(np.zeros((4, 4)), np.zeros((4, 1)), [1.0], 1.0, 1e-3, 0.0)       # D = 4: documented narrowing
+        h.fit(np.zeros((4, 9)), np.zeros((4, 1)), [1.0], 1.0, 1e-3, 0.0)       # D = 9: beyond the documented limit of 8
 
 
 def test_covariance_needs_the_inverse_factor_of_the_committed_model():

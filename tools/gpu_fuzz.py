@@ -27,11 +27,11 @@ h = _lib.Handle(0)
 for it in range(cases):
     N = int(rng.choice([1, 2, 5, 17, 63, 64, 65, 130, 257, 511, 513, 777, 1025, 1500, 2100, 3000]))
     M = int(rng.choice([1, 7, 64, 65, 300, 1000, 4097, 17000, 40000]))      # cut sweeps only / whole rounds + tail
-    D = int(rng.integers(1, 4))
+    D = int(rng.integers(1, 9)) if rng.integers(0, 3) else int(rng.integers(1, 4))      # 4 .. 8: the wide layout
     O = int(rng.integers(1, 7))
     kind = str(rng.choice(["rbf", "rbf", "rbf", "matern12", "matern32", "matern52"]))
     iso = bool(rng.integers(0, 2))
-    ls = np.exp(rng.uniform(np.log(0.03), np.log(2.0), 1 if iso else D))
+    ls = np.exp(rng.uniform(np.log(0.03), np.log(2.0), 1 if iso else D)) * (1.0 if D <= 3 else 2.0 * np.sqrt(D / 3.0))
     c = float(np.exp(rng.uniform(np.log(1e-2), np.log(30.0))))
     noise = float(np.exp(rng.uniform(np.log(1e-6), np.log(1e-1)))) * c
     jit = 1e-10
@@ -91,7 +91,7 @@ worst2, bad2 = {}, 0
 for it in range(max(cases // 2, 6)):
     Z = int(rng.choice([3, 64, 130, 511, 513, 900, 1500, 2048]))
     T = int(rng.integers(1, 6))
-    D = int(rng.integers(1, 4))
+    D = int(rng.integers(1, 9))
     M = int(rng.choice([1, 65, 460, 3000, 20000]))
     dtype = int(rng.integers(0, 2))
     Zp = rng.uniform(0, 1, (Z, D))
@@ -99,7 +99,7 @@ for it in range(max(cases // 2, 6)):
     Sigma = A @ A.transpose(0, 2, 1) / Z * float(np.exp(rng.uniform(np.log(1e-3), 0))) + 1e-3 * np.eye(Z)
     y = rng.standard_normal((T, Z))
     osc = np.exp(rng.uniform(np.log(0.1), np.log(5.0), T))
-    ls = np.exp(rng.uniform(np.log(0.08), np.log(1.0), D))
+    ls = np.exp(rng.uniform(np.log(0.08), np.log(1.0), D)) * (1.0 if D <= 3 else 2.0 * np.sqrt(D / 3.0))
     Xq = rng.uniform(-0.1, 1.1, (M, D))
     tag = f"svgp case {it}: Z={Z} T={T} D={D} M={M} {'fp32' if dtype else 'fp64'}"
     hs = _lib.Handle(0)
