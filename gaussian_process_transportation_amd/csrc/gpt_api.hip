@@ -159,6 +159,7 @@ struct gpt_handle {
     int n_ls = 1;
     // fit workspace (fp64)
     double *dK = nullptr, *dW = nullptr, *dY4 = nullptr, *dT4 = nullptr, *dTa = nullptr, *dXs64 = nullptr, *dA64 = nullptr, *dscal = nullptr;
+    double* dXraw = nullptr;       // the raw (N, D) sources as uploaded; scaled on the device for every new set of length-scales
     double* dScr = nullptr;        // scratch of the triangular inverse (NP^2/4) and of alpha's backward pass
     int* dinfo = nullptr;
     int64_t ws_np = 0;
@@ -166,7 +167,13 @@ struct gpt_handle {
     bool have_L = false;           // dK holds L of the committed model (gpt_export, gpt_lml)
     bool have_W = false;           // dW holds L^-1 of the committed model (gpt_predict_cov, gpt_lml_gradient, gpt_export_inverse_factor)
     bool objective_ready = false;  // gpt_lml_objective: factor and alpha in the workspace, no committed model
-    std::vector<double> hostY;     // filtered targets (N,O) for the LML
+    // Host mirrors of what dXraw / dY4 hold, (N, D) and (N, O): a fit with the same X / Y (every evaluation of the
+    // optimizer's objective) uploads nothing.  Cleared whenever the device copies are lost or overwritten.
+    std::vector<double> hostX, hostY, hostY4;
+    int hostX_D = 0, hostY_O = 0;
+    double host_scal[16] = {};     // landing area of the per-fit scalar read-back
+    double host_hdr[HDR_DOUBLES] = {};
+    int host_info = 0;
     // staging of the host-pointer API, grow-only per buffer
     // (two sets: while the results of one chunk travel to the host on `copy_stream`, the next chunk computes)
     struct Staging { void* buf[ST_COUNT] = {}; size_t bytes[ST_COUNT] = {}; } st[2];
@@ -203,7 +210,8 @@ void free_staging(gpt_handle* h) {
 }
 
 void free_workspace(gpt_handle* h) {
-    double** ptrs[] = {&h->dK, &h->dW, &h->dY4, &h->dT4, &h->dTa, &h->dXs64, &h->dA64, &h->dscal, &h->dScr};
+    double** ptrs[] = {&h->dK, &h->dW, &h->dY4, &h->dT4, &h->dTa, &h->dXs64, &h->dA64, &h->dscal, &h->dScr, &h->dXraw};
+    h->hostX.clear(); h->hostY.clear();
     for (auto pp : ptrs) { if (*pp) (void)hipFree(*pp); *pp = nullptr; }
     if (h->dinfo) (void)hipFree(h->dinfo);
     h->dinfo = nullptr;
@@ -235,6 +243,7 @@ int ensure_workspace(gpt_handle* h, int64_t NP, int npass) {
     HIPCHK(hipMalloc(&h->dT4, (size_t)NP * 4 * sizeof(double)));
     HIPCHK(hipMalloc(&h->dTa, (size_t)NP * 4 * sizeof(double)));
     HIPCHK(hipMalloc(&h->dXs64, (size_t)NP * MAX_D * sizeof(double)));
+    HIPCHK(hipMalloc(&h->dXraw, (size_t)NP * MAX_D * sizeof(double)));
     HIPCHK(hipMalloc(&h->dscal, 16 * sizeof(double)));
     HIPCHK(hipMalloc(&h->dinfo, sizeof(int)));
     {
@@ -294,10 +303,12 @@ int check_geometry(const char* who, int64_t N, int D, int O, const double* lengt
     return GPT_OK;
 }
 
-// Header + scaled, padded sources: to the fp64 workspace image (what the fit kernels read) and, in the model's element
-// type, to the blob.  hdr is complete on return (task priors at hdr[16..] are the caller's).
+// Header + scaled, padded sources: to the fp64 workspace image (what the fit kernels read) and, when `model`, in the
+// model's element type to the blob.  hdr is complete on return (task priors at hdr[16..] are the caller's).  Nothing here
+// waits for the device: the raw sources are uploaded only when they differ from what the device already holds, the scaling
+// by the length-scales runs on the device.
 int upload_sources(gpt_handle* h, const Layout& l, const double* X, std::vector<double>& hdr, const double* length_scale,
-                   int n_ls, double constant_value, double noise_level, double alpha_jitter, int kernel_type) {
+                   int n_ls, double constant_value, double noise_level, double alpha_jitter, int kernel_type, bool model) {
     hdr.assign(HDR_DOUBLES, 0.0);
     hdr[0] = MAGIC; hdr[1] = (double)l.N; hdr[2] = (double)l.NP; hdr[3] = l.D; hdr[4] = l.O;
     hdr[5] = constant_value; hdr[6] = noise_level; hdr[7] = alpha_jitter;
@@ -305,21 +316,29 @@ int upload_sources(gpt_handle* h, const Layout& l, const double* X, std::vector<
     for (int d = 0; d < l.D; ++d) hdr[hdr_ls_slot(d)] = length_scale[n_ls == 1 ? 0 : d];
     hdr[11] = n_ls; hdr[12] = l.npass; hdr[13] = kernel_type; hdr[14] = l.ntask; hdr[15] = l.dtype;
     fill_params(h, hdr.data());
-    const size_t NP = (size_t)l.NP;
-    const size_t XS = (size_t)xs_stride(l.D);
-    std::vector<double> xs(NP * XS, 0.0);
-    for (int64_t i = 0; i < l.N; ++i)
-        for (int d = 0; d < l.D; ++d) xs[(size_t)i * XS + d] = X[i * l.D + d] * h->p.inv_ls[d];
     hipStream_t s = h->stream;
-    HIPCHK(hipMemcpyAsync(h->dXs64, xs.data(), xs.size() * sizeof(double), hipMemcpyHostToDevice, s));
-    if (l.dtype == DT_F32) {
-        std::vector<float> xf(xs.begin(), xs.end());
-        HIPCHK(hipMemcpyAsync(h->dXs(), xf.data(), xf.size() * sizeof(float), hipMemcpyHostToDevice, s));
-        HIPCHK(hipStreamSynchronize(s));
-    } else {
-        HIPCHK(hipMemcpyAsync(h->dXs(), xs.data(), xs.size() * sizeof(double), hipMemcpyHostToDevice, s));
-        HIPCHK(hipStreamSynchronize(s));   // host vectors go out of scope
+    const size_t nx = (size_t)l.N * l.D;
+    if (h->hostX.size() != nx || h->hostX_D != l.D || memcmp(h->hostX.data(), X, nx * sizeof(double)) != 0) {
+        HIPCHK(hipStreamSynchronize(s));     // (a copy out of the old mirror that an aborted call left in flight)
+        h->hostX.assign(X, X + nx);          // the mirror is also the source of the asynchronous copy: it outlives the call
+        h->hostX_D = l.D;
+        HIPCHK(hipMemcpyAsync(h->dXraw, h->hostX.data(), nx * sizeof(double), hipMemcpyHostToDevice, s));
     }
+    launch_scale_x(s, h->dXraw, (int)l.N, (int)l.NP, l.D, h->p.inv_ls, h->dXs64, model ? h->dXs() : nullptr, l.dtype);
+    return GPT_OK;
+}
+
+// Padded targets [pass][NP][4] into dY4, unless the device already holds exactly these (N, O) values.
+int upload_targets(gpt_handle* h, const Layout& l, const double* Y) {
+    const size_t ny = (size_t)l.N * l.O, NP = (size_t)l.NP;
+    if (h->hostY.size() == ny && h->hostY_O == l.O && memcmp(h->hostY.data(), Y, ny * sizeof(double)) == 0) return GPT_OK;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->hostY.assign(Y, Y + ny);
+    h->hostY_O = l.O;
+    h->hostY4.assign((size_t)l.npass * NP * 4, 0.0);
+    for (int64_t i = 0; i < l.N; ++i)
+        for (int o = 0; o < l.O; ++o) h->hostY4[((size_t)(o / 4) * NP + i) * 4 + (o % 4)] = Y[i * l.O + o];
+    HIPCHK(hipMemcpyAsync(h->dY4, h->hostY4.data(), h->hostY4.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
     return GPT_OK;
 }
 
@@ -450,11 +469,12 @@ static int read_fit_times(gpt_handle* h) {
     return GPT_OK;
 }
 
-// model = false: what one evaluation of the optimizer's objective needs (L, W, alpha in the fp64 workspace) and nothing of the
-// prediction-side model (no alpha / W in the blob's layouts): the handle is left without a committed model.
-static int fit_impl(gpt_handle* h, const double* X, const double* Y, int64_t N, int D, int O,
-                    const double* length_scale, int n_ls, double constant_value, double noise_level,
-                    double alpha_jitter, int kernel_type, const double* Sigma, bool model) {
+// Everything of a fit up to the last kernel, nothing waited for.  model = false: what one evaluation of the optimizer's
+// objective needs (L, W, alpha in the fp64 workspace) and nothing of the prediction-side model (no sources / alpha / W in
+// the blob's layouts).
+static int fit_enqueue(gpt_handle* h, const double* X, const double* Y, int64_t N, int D, int O,
+                       const double* length_scale, int n_ls, double constant_value, double noise_level,
+                       double alpha_jitter, int kernel_type, const double* Sigma, bool model) {
     if (!h || !X || !Y || !length_scale) return fail(GPT_E_ARG, "gpt_fit: NULL argument");
     if (kernel_type < GPT_KERNEL_RBF || kernel_type > GPT_KERNEL_MATERN52) return fail(GPT_E_ARG, "gpt_fit: unknown kernel_type");
     if (int rc = check_geometry("gpt_fit", N, D, O, length_scale, n_ls)) return rc;
@@ -470,17 +490,15 @@ static int fit_impl(gpt_handle* h, const double* X, const double* Y, int64_t N, 
     const int NP = (int)l.NP;
     hipStream_t s = h->stream;
 
-    // ---- host preparation: header, scaled + padded sources, padded targets
+    // ---- inputs: header, sources (scaled on the device), padded targets; copies only of what the device does not hold yet
     std::vector<double> hdr;
-    if (int rc = upload_sources(h, l, X, hdr, length_scale, n_ls, constant_value, noise_level, alpha_jitter, kernel_type)) return rc;
-    hdr[HDR_TASK_C] = constant_value;
-    std::vector<double> y4((size_t)l.npass * NP * 4, 0.0);
-    for (int64_t i = 0; i < N; ++i)
-        for (int o = 0; o < O; ++o) y4[((size_t)(o / 4) * NP + i) * 4 + (o % 4)] = Y[i * O + o];
-    h->hostY.assign(Y, Y + (size_t)N * O);
-    HIPCHK(hipMemcpyAsync(h->blob, hdr.data(), HDR_DOUBLES * sizeof(double), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(h->dY4, y4.data(), y4.size() * sizeof(double), hipMemcpyHostToDevice, s));
-    HIPCHK(hipStreamSynchronize(s));   // host vectors go out of scope below
+    if (int rc = upload_sources(h, l, X, hdr, length_scale, n_ls, constant_value, noise_level, alpha_jitter, kernel_type, model)) return rc;
+    if (int rc = upload_targets(h, l, Y)) return rc;
+    if (model) {
+        hdr[HDR_TASK_C] = constant_value;
+        memcpy(h->host_hdr, hdr.data(), sizeof h->host_hdr);          // a member: the source of an asynchronous copy
+        HIPCHK(hipMemcpyAsync(h->blob, h->host_hdr, sizeof h->host_hdr, hipMemcpyHostToDevice, s));
+    }
 
     // ---- device pipeline
     HIPCHK(hipEventRecord(h->ev[0], s));
@@ -497,13 +515,15 @@ static int fit_impl(gpt_handle* h, const double* X, const double* Y, int64_t N, 
     }
     HIPCHK(hipEventRecord(h->ev[5], s));
     HIPCHK(hipGetLastError());
-    int info = 0;
-    HIPCHK(hipMemcpyAsync(&info, h->dinfo, sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    if (int rc = read_fit_times(h)) return rc;
-    if (info != 0) {
+    HIPCHK(hipMemcpyAsync(&h->host_info, h->dinfo, sizeof(int), hipMemcpyDeviceToHost, s));
+    return GPT_OK;
+}
+
+// After the stream has been synchronised: the pivot check and the state of the handle.
+static int fit_finish(gpt_handle* h, bool model) {
+    if (h->host_info != 0) {
         char buf[160];
-        snprintf(buf, sizeof buf, "gpt_fit: kernel matrix is not positive definite (pivot %d <= 0)", info);
+        snprintf(buf, sizeof buf, "gpt_fit: kernel matrix is not positive definite (pivot %d <= 0)", h->host_info);
         return fail(GPT_E_NOT_PD, buf);
     }
     h->committed = model;
@@ -512,13 +532,77 @@ static int fit_impl(gpt_handle* h, const double* X, const double* Y, int64_t N, 
     return GPT_OK;
 }
 
+static int fit_impl(gpt_handle* h, const double* X, const double* Y, int64_t N, int D, int O,
+                    const double* length_scale, int n_ls, double constant_value, double noise_level,
+                    double alpha_jitter, int kernel_type, const double* Sigma, bool model) {
+    if (int rc = fit_enqueue(h, X, Y, N, D, O, length_scale, n_ls, constant_value, noise_level, alpha_jitter, kernel_type, Sigma, model)) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (int rc = read_fit_times(h)) return rc;
+    return fit_finish(h, model);
+}
+
+// ---- log-marginal likelihood and its gradient: device-side reductions into dscal, one read-back
+//   dscal[0] = sum_i log L_ii, dscal[1] = sum_o y_o^T alpha_o, dscal[2 ..] = the LML_TERMS traces of the gradient
+static void enqueue_lml_scalars(gpt_handle* h) {
+    launch_logdet(h->stream, h->dK, h->p.N, h->p.NP, h->dscal);
+    launch_dot(h->stream, h->dY4, h->dA64, (int64_t)h->lay.npass * h->p.NP * 4, h->dscal + 1);
+}
+
+static int enqueue_gradient_terms(gpt_handle* h) {
+    const int64_t NP = h->p.NP;
+    hipStream_t s = h->stream;
+    // K^-1 (lower) into dK, per-tile partial sums into their own scratch
+    const size_t need = (size_t)(NP / 64) * (NP / 64) * LML_PARTIAL_STRIDE;
+    if (need > h->lml_partial_cap) {
+        HIPCHK(hipStreamSynchronize(s));
+        if (h->lml_partial) (void)hipFree(h->lml_partial);
+        h->lml_partial = nullptr; h->lml_partial_cap = 0;
+        HIPCHK(hipMalloc(&h->lml_partial, need * sizeof(double)));
+        h->lml_partial_cap = need;
+    }
+    launch_kinv(s, h->dW, (int)NP, h->dK);
+    launch_lml_terms(s, h->dXs64, h->p.D, h->dA64, h->lay.npass, h->dK, h->p.N, (int)NP, h->p.O, h->p.ktype, h->p.c, h->lml_partial, h->dscal + 2);
+    HIPCHK(hipGetLastError());
+    return GPT_OK;
+}
+
+static double lml_from_scalars(const gpt_handle* h, const double* sc) {
+    // sum over outputs of  -1/2 y^T alpha - sum log L_ii - N/2 log 2 pi   (sklearn/_gpr.py:598-606)
+    const double O = h->p.O, N = h->p.N;
+    return -0.5 * sc[1] - O * sc[0] - 0.5 * O * N * std::log(2.0 * M_PI);
+}
+
+static void gradient_from_scalars(const gpt_handle* h, const double* S, double* grad) {
+    // theta = log [constant_value, length_scale (1 or D), noise_level]
+    const int D = h->p.D;
+    grad[0] = 0.5 * S[0];
+    if (h->n_ls == 1) {
+        double t = 0;
+        for (int d = 0; d < D; ++d) t += S[1 + d];
+        grad[1] = 0.5 * t;
+    } else {
+        for (int d = 0; d < D; ++d) grad[1 + d] = 0.5 * S[1 + d];
+    }
+    grad[1 + h->n_ls] = 0.5 * h->p.noise * S[LML_TERMS - 1];
+}
+
+// One evaluation of the optimizer's objective: everything enqueued back to back, ONE wait, one read-back.
 int gpt_lml_objective(gpt_handle* h, const double* X, const double* Y, int64_t N, int D, int O,
                       const double* length_scale, int n_ls, double constant_value, double noise_level,
                       double alpha_jitter, int kernel_type, double* lml, double* grad) {
     if (!lml || !grad) return fail(GPT_E_ARG, "gpt_lml_objective: NULL argument");
-    if (int rc = fit_impl(h, X, Y, N, D, O, length_scale, n_ls, constant_value, noise_level, alpha_jitter, kernel_type, nullptr, false))
+    if (int rc = fit_enqueue(h, X, Y, N, D, O, length_scale, n_ls, constant_value, noise_level, alpha_jitter, kernel_type, nullptr, false))
         return rc;
-    return gpt_lml_gradient(h, lml, grad);
+    hipStream_t s = h->stream;
+    enqueue_lml_scalars(h);                                   // reads diag(L) in dK before the gradient overwrites it
+    if (int rc = enqueue_gradient_terms(h)) return rc;
+    HIPCHK(hipMemcpyAsync(h->host_scal, h->dscal, (2 + LML_TERMS) * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (int rc = fit_finish(h, false)) return rc;             // not positive definite: whatever ran behind the factor is discarded
+    h->have_L = false;                                        // dK holds K^-1 now
+    *lml = lml_from_scalars(h, h->host_scal);
+    gradient_from_scalars(h, h->host_scal + 2, grad);
+    return GPT_OK;
 }
 
 int gpt_fit_svgp(gpt_handle* h, const double* Z, const double* y, const double* Sigma, int64_t N, int D, int T,
@@ -542,7 +626,7 @@ int gpt_fit_svgp(gpt_handle* h, const double* Z, const double* y, const double* 
     // the kernel columns are generated WITHOUT the outputscale (c = 1): it is folded into each task's inverse factor
     // and alpha, so that all tasks share one B operand
     std::vector<double> hdr;
-    if (int rc = upload_sources(h, l, Z, hdr, length_scale, n_ls, 1.0, 0.0, jitter, GPT_KERNEL_RBF)) return rc;
+    if (int rc = upload_sources(h, l, Z, hdr, length_scale, n_ls, 1.0, 0.0, jitter, GPT_KERNEL_RBF, true)) return rc;
     for (int t = 0; t < T; ++t) hdr[HDR_TASK_C + t] = outputscale[t];
     HIPCHK(hipMemcpyAsync(h->blob, hdr.data(), HDR_DOUBLES * sizeof(double), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemsetAsync(h->dA4(), 0, (size_t)l.npass * NP * 4 * l.esz, s));
@@ -757,20 +841,10 @@ int gpt_lml(gpt_handle* h, double* lml) {
     if (!h || !lml) return fail(GPT_E_ARG, "gpt_lml: NULL argument");
     if (!(h->committed || h->objective_ready) || !h->have_L || !h->have_W) return fail(GPT_E_STATE, "gpt_lml: needs the handle that ran gpt_fit");
     if (int rc = set_device(h)) return rc;
-    const int64_t N = h->p.N, NP = h->p.NP;
-    const int O = h->p.O;
-    launch_logdet(h->stream, h->dK, (int)N, (int)NP, h->dscal);
-    double logdet = 0;
-    HIPCHK(hipMemcpyAsync(&logdet, h->dscal, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    std::vector<double> a4;
-    if (int rc = fetch_alpha(h, a4)) return rc;
-    double total = 0;
-    for (int o = 0; o < O; ++o) {
-        double ya = 0;
-        for (int64_t i = 0; i < N; ++i) ya += h->hostY[i * O + o] * a4[((size_t)(o / 4) * NP + i) * 4 + (o % 4)];
-        total += -0.5 * ya - logdet - 0.5 * (double)N * std::log(2.0 * M_PI);
-    }
-    *lml = total;
+    enqueue_lml_scalars(h);
+    HIPCHK(hipMemcpyAsync(h->host_scal, h->dscal, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *lml = lml_from_scalars(h, h->host_scal);
     return GPT_OK;
 }
 
@@ -816,36 +890,14 @@ int gpt_predict_cov(gpt_handle* h, const double* Xq, int64_t M, double* mean, do
 int gpt_lml_gradient(gpt_handle* h, double* lml, double* grad) {
     if (!h || !lml || !grad) return fail(GPT_E_ARG, "gpt_lml_gradient: NULL argument");
     if (!(h->committed || h->objective_ready) || !h->have_L || !h->have_W) return fail(GPT_E_STATE, "gpt_lml_gradient: needs the handle that ran gpt_fit");
-    if (int rc = gpt_lml(h, lml)) return rc;                    // uses diag(L) in dK before it is overwritten
-    const int64_t N = h->p.N, NP = h->p.NP;
-    const int D = h->p.D, O = h->p.O;
-    hipStream_t s = h->stream;
-    // K^-1 (lower) into dK, per-tile partial sums into their own scratch
-    const size_t need = (size_t)(NP / 64) * (NP / 64) * LML_PARTIAL_STRIDE;
-    if (need > h->lml_partial_cap) {
-        HIPCHK(hipStreamSynchronize(s));
-        if (h->lml_partial) (void)hipFree(h->lml_partial);
-        h->lml_partial = nullptr; h->lml_partial_cap = 0;
-        HIPCHK(hipMalloc(&h->lml_partial, need * sizeof(double)));
-        h->lml_partial_cap = need;
-    }
+    if (int rc = set_device(h)) return rc;
+    enqueue_lml_scalars(h);                                      // uses diag(L) in dK before it is overwritten
     h->have_L = false;                                           // L is gone: gpt_export(L) needs a new gpt_fit (W stays valid)
-    launch_kinv(s, h->dW, (int)NP, h->dK);
-    launch_lml_terms(s, h->dXs64, D, h->dA64, h->lay.npass, h->dK, (int)N, (int)NP, O, h->p.ktype, h->p.c, h->lml_partial, h->dscal);
-    HIPCHK(hipGetLastError());
-    double S[LML_TERMS];
-    HIPCHK(hipMemcpyAsync(S, h->dscal, sizeof S, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    // theta = log [constant_value, length_scale (1 or D), noise_level]
-    grad[0] = 0.5 * S[0];
-    if (h->n_ls == 1) {
-        double t = 0;
-        for (int d = 0; d < D; ++d) t += S[1 + d];
-        grad[1] = 0.5 * t;
-    } else {
-        for (int d = 0; d < D; ++d) grad[1 + d] = 0.5 * S[1 + d];
-    }
-    grad[1 + h->n_ls] = 0.5 * h->p.noise * S[LML_TERMS - 1];
+    if (int rc = enqueue_gradient_terms(h)) return rc;
+    HIPCHK(hipMemcpyAsync(h->host_scal, h->dscal, (2 + LML_TERMS) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *lml = lml_from_scalars(h, h->host_scal);
+    gradient_from_scalars(h, h->host_scal + 2, grad);
     return GPT_OK;
 }
 

@@ -70,6 +70,9 @@ struct KernelParams {
 // fit
 void launch_gram(hipStream_t s, const double* Xs, int D, int N, int NP, int ktype, double c, double diag_add, double* K);
 void launch_add_lower(hipStream_t s, double* K, const double* S, int N, int NP);
+// raw (N, D) sources on the device -> scaled, padded rows (fp64 workspace image; Xm, may be null: the model's copy in dtype)
+void launch_scale_x(hipStream_t s, const double* X, int N, int NP, int D, const double* inv_ls /* host, MAX_D */, double* Xs64, void* Xm, int dtype);
+void launch_dot(hipStream_t s, const double* a, const double* b, int64_t n, double* out);
 // Streams and events of the overlapped factor + inverse pipeline, owned by a handle: two streams confined to disjoint
 // halves of the CUs (hipExtStreamCreateWithCUMask).  Created on first use; `ok` false = unavailable, everything runs in
 // the caller's stream.

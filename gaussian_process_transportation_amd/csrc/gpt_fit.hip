@@ -15,6 +15,8 @@
 
 namespace gpt {
 
+struct InvLs { double v[MAX_D]; };       // 1 / length_scale per dimension, by value to the kernels that scale coordinates
+
 // =====================================================================================
 // Gram assembly: K[i][j] = c * exp(-0.5 |xs_i - xs_j|^2) (+ diag_add on the diagonal) for the
 // block lower triangle; padded rows/cols get the identity so the factorisation stays PD.
@@ -71,6 +73,50 @@ void launch_gram(hipStream_t s, const double* Xs, int D, int N, int NP, int ktyp
     dim3 grid(NP / 64, NP / 64);
     if (D <= 3) hipLaunchKernelGGL(k_gram<3>, grid, dim3(256), 0, s, Xs, N, NP, ktype, c, diag_add, K);
     else hipLaunchKernelGGL(k_gram<MAX_D>, grid, dim3(256), 0, s, Xs, N, NP, ktype, c, diag_add, K);
+}
+
+// Xs[i][d] = X[i][d] / l_d for i < N, d < D, zero elsewhere (rows of 4 or 8: xs_stride): the fp64 image the fit kernels
+// read and, when Xm is given, the model's copy in its element type.  X is the raw (N, D) row-major input, kept on the
+// device so that a new set of length-scales (every evaluation of the optimizer's objective) costs no host work and no copy.
+template <typename TM>
+__global__ __launch_bounds__(256) void k_scale_x(const double* __restrict__ X, int N, int NP, int D, int XS, InvLs il,
+                                                 double* __restrict__ Xs64, TM* __restrict__ Xm) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= NP) return;
+#pragma unroll
+    for (int d = 0; d < MAX_D; ++d) {
+        if (d >= XS) break;
+        const double v = (i < N && d < D) ? X[(size_t)i * D + d] * il.v[d] : 0.0;
+        Xs64[(size_t)i * XS + d] = v;
+        if (Xm) Xm[(size_t)i * XS + d] = (TM)v;
+    }
+}
+
+void launch_scale_x(hipStream_t s, const double* X, int N, int NP, int D, const double* inv_ls, double* Xs64, void* Xm, int dtype) {
+    InvLs il;
+    for (int d = 0; d < MAX_D; ++d) il.v[d] = inv_ls[d];
+    const dim3 grid((NP + 255) / 256);
+    if (dtype == DT_F32) hipLaunchKernelGGL(k_scale_x<float>, grid, dim3(256), 0, s, X, N, NP, D, xs_stride(D), il, Xs64, static_cast<float*>(Xm));
+    else hipLaunchKernelGGL(k_scale_x<double>, grid, dim3(256), 0, s, X, N, NP, D, xs_stride(D), il, Xs64, static_cast<double*>(Xm));
+}
+
+// out[0] = sum_i a[i] b[i], one workgroup, fixed order (deterministic): sum_o y_o^T alpha_o of the LML over the padded
+// [pass][NP][4] images (padding is zero on both sides).
+__global__ __launch_bounds__(256) void k_dot(const double* __restrict__ a, const double* __restrict__ b, int64_t n, double* __restrict__ out) {
+    __shared__ double red[256];
+    double sacc = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) sacc = fma(a[i], b[i], sacc);
+    red[threadIdx.x] = sacc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = red[0];
+}
+
+void launch_dot(hipStream_t s, const double* a, const double* b, int64_t n, double* out) {
+    hipLaunchKernelGGL(k_dot, dim3(1), dim3(256), 0, s, a, b, n, out);
 }
 
 // K[i][j] += S[i][j] on the lower triangle of the first N rows (S row-major N x N, symmetric): the general
@@ -1191,8 +1237,6 @@ void launch_lml_terms(hipStream_t s, const double* Xs, int D, const double* A4, 
 // Posterior covariance  cov = k(Xq,Xq) + noise*I - V^T V,  V = W K*^T  (sklearn/_gpr.py:458-468,
 // where V = L \ K*^T).  Small-M path (sampling, return_cov): K*^T and V are materialised (NP x Mp).
 // =====================================================================================
-struct InvLs { double v[MAX_D]; };
-
 __global__ __launch_bounds__(256) void k_cross_t(const double* __restrict__ Xs, const double* __restrict__ Xq, int N, int NP,
                                                  int64_t M, int Mp, int D, int XS, int ktype, double c, InvLs il,
                                                  double* __restrict__ KsT /* [NP][Mp] */) {

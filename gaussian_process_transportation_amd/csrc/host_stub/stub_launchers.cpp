@@ -21,6 +21,11 @@ size_t wf_overrun_elems() { return WT_STEP_DOUBLES; }
 void launch_gram(hipStream_t, const double* Xs, int D, int, int NP, int, double, double, double* K) {
     touch_r(Xs, (size_t)NP * xs_stride(D) * 8); touch_w(K, (size_t)NP * NP * 8);
 }
+void launch_scale_x(hipStream_t, const double* X, int N, int NP, int D, const double* inv_ls, double* Xs64, void* Xm, int dtype) {
+    touch_r(X, (size_t)N * D * 8); touch_r(inv_ls, MAX_D * 8); touch_w(Xs64, (size_t)NP * xs_stride(D) * 8);
+    touch_w(Xm, (size_t)NP * xs_stride(D) * esz(dtype));
+}
+void launch_dot(hipStream_t, const double* a, const double* b, int64_t n, double* out) { touch_r(a, (size_t)n * 8); touch_r(b, (size_t)n * 8); *out = 0.0; }
 void launch_add_lower(hipStream_t, double* K, const double* S, int N, int NP) { touch_r(S, (size_t)N * N * 8); touch_w(K, (size_t)NP * NP * 8); }
 void fit_aux_release(FitAux&) {}
 size_t factor_scratch_doubles(int NP) { return (size_t)NP * NP / 4 + (size_t)NP * NP / 16 + 4096; }

@@ -30,6 +30,20 @@ def _unpack(kernel, theta):
     return float(p[_PARAM_C]), np.atleast_1d(np.asarray(p[_PARAM_LS], dtype=np.float64)), float(p[_PARAM_NOISE])
 
 
+def _make_unpack(kernel, free, n_ls):
+    """The same map without cloning the kernel (sklearn's clone costs more than the GPU's share of a small objective
+    evaluation): the full parameter vector [c, ls.., noise] with the fixed entries filled in once, the free ones
+    exp(theta) as the kernel's theta setter does (sklearn/gaussian_process/kernels.py: `np.exp(theta[i:...])`)."""
+    p = kernel.get_params()
+    fixed = np.concatenate([[float(p[_PARAM_C])], np.atleast_1d(np.asarray(p[_PARAM_LS], dtype=np.float64)), [float(p[_PARAM_NOISE])]])
+
+    def unpack(theta):
+        v = fixed.copy()
+        v[free] = np.exp(theta)
+        return float(v[0]), v[1:1 + n_ls].copy(), float(v[1 + n_ls])
+    return unpack
+
+
 def _free_mask(kernel, n_ls):
     """Which entries of the full gradient [c, ls (n_ls), noise] belong to theta (hyper-parameters whose
     bounds are not "fixed"), in theta order."""
@@ -58,8 +72,10 @@ def optimize_hyperparameters(gp, c0, ls0, noise0):
     X = _lib.as_f64(gp.X, 2, "X")                          # validated once; every evaluation reuses these arrays
     Y = _lib.as_f64(gp.Y, 2, "y")
 
+    unpack = _make_unpack(kernel, free, n_ls)
+
     def objective(theta):
-        c, ls, noise = _unpack(kernel, theta)
+        c, ls, noise = unpack(theta)
         try:
             lml, grad = h.lml_objective(X, Y, ls, c, noise, jitter, gp._ktype)     # one C call, no prediction-side model
         except np.linalg.LinAlgError:                      # _gpr.py:587-590: -inf LML, zero gradient
