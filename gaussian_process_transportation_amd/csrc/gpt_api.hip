@@ -69,18 +69,18 @@ enum { ST_Q = 0, ST_MEAN, ST_VAR, ST_J, ST_JVAR, ST_DVAR, ST_COUNT };
 namespace gpt {
 
 int var_workgroups() {
-    static int n[MAX_DEVICES] = {};
+    static std::atomic<int> n[MAX_DEVICES] = {};       // (threads may race to fill it: they compute the same value)
     const int dev = current_device();
-    if (n[dev] == 0) {
+    if (n[dev].load() == 0) {
         int v = 0;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) == hipSuccess) v = prop.multiProcessorCount;
         if (v <= 0) v = 256;
         const char* e = getenv("GPT_VAR_WGS");
         if (e && atoi(e) > 0) v = atoi(e);
-        n[dev] = v;
+        n[dev].store(v);
     }
-    return n[dev];
+    return n[dev].load();
 }
 
 // ncomp: 1 = k* alone; 3 = Jacobian variance alone, D columns per query (D <= 3); 4 / 8 / 16 = var_fused_cols(D)

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <atomic>
+#include <mutex>
 #include <cstdint>
 #include <cstddef>
 
@@ -47,8 +48,10 @@ inline int current_device() {
     return d;
 }
 struct PerDeviceOnce {
-    std::atomic<bool> done[MAX_DEVICES] = {};
-    bool first() { return !done[current_device()].exchange(true); }      // true exactly once per device
+    std::once_flag flags[MAX_DEVICES];
+    // f runs exactly once per device; callers arriving meanwhile (handles on other threads: the optimizer's concurrent
+    // restarts) wait until it has finished, so nobody launches a kernel before its attributes are set
+    template <class F> void run(F&& f) { std::call_once(flags[current_device()], f); }
 };
 
 // Model parameters passed by value to the prediction kernels.

@@ -707,8 +707,7 @@ static void launch_gemm_ts(hipStream_t s, const GemmArgs& g) {
     const GemmGrid q = gemm_grid(g, TS);
     constexpr size_t lds = (size_t)((AT ? 32 * (TS + 16) : TS * GA_S) + (BT ? TS * GA_S : 32 * (TS + 16))) * sizeof(double);
     static PerDeviceOnce once;
-    if (once.first())
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<BT, AT, TS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    once.run([&] { hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<BT, AT, TS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
     hipLaunchKernelGGL((k_gemm<BT, AT, TS>), dim3(q.nvid), dim3(256), lds, s, g, q.TM, q.TN, q.G, q.fold_tm);
 }
 
@@ -759,10 +758,10 @@ static void potrf_groups(hipStream_t s, double* K, double* W, int NP, int* info,
     constexpr size_t step_lds = (size_t)(2 * NB * PS) * sizeof(double);
     constexpr size_t fin_lds = (size_t)(2 * NB * DS) * sizeof(double);
     static PerDeviceOnce once;
-    if (once.first()) {
+    once.run([&] {
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_step), hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_finish), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fin_lds);
-    }
+    });
     // Third level: panels are grouped by `grp`.  Inside a group a panel's own columns receive the group's earlier panels
     // just before its steps (a thin GEMM, K = up to (grp-1) panels); everything behind the group is updated once per
     // group with K = grp panels — the read-modify-write of the trailing matrix, which bounds the rank-128 update
@@ -1080,10 +1079,10 @@ void launch_pack_w(hipStream_t s, const double* W, int N, int NP, void* Wf, int 
     const int nbt = NP / WT;
     const size_t lds = (size_t)PKR * PK_S * sizeof(double);
     static PerDeviceOnce once;
-    if (once.first()) {
+    once.run([&] {
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_pack_w<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_pack_w<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    }
+    });
     const dim3 grid(nbt * (WT / PKC), nbt * (WT / PKR));
     const size_t off = (size_t)task * wf_elems(NP);
     if (dtype == DT_F32) hipLaunchKernelGGL(k_pack_w<float>, grid, dim3(256), lds, s, W, N, NP, static_cast<float*>(Wf) + off, scale);

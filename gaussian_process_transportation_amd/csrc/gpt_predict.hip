@@ -787,7 +787,7 @@ __global__ __launch_bounds__(64) void k_var_finalize(KernelParams p, VarPlanDev 
 template <typename T>
 static void var_kernel_setup() {
     static PerDeviceOnce once;
-    if (!once.first()) return;
+    once.run([] {
     const void* fns[] = {reinterpret_cast<const void*>(k_var<T, 1, false, KT_RBF>), reinterpret_cast<const void*>(k_var<T, 4, true, KT_RBF>),
                          reinterpret_cast<const void*>(k_var<T, 4, false, KT_RBF>), reinterpret_cast<const void*>(k_var<T, 3, false, KT_RBF>),
                          reinterpret_cast<const void*>(k_var<T, 1, false, KT_MATERN12>),
@@ -798,6 +798,7 @@ static void var_kernel_setup() {
                          reinterpret_cast<const void*>(k_var<T, 8, true, KT_RBF, MAX_D>), reinterpret_cast<const void*>(k_var<T, 8, false, KT_RBF, MAX_D>),
                          reinterpret_cast<const void*>(k_var<T, 16, true, KT_RBF, MAX_D>), reinterpret_cast<const void*>(k_var<T, 16, false, KT_RBF, MAX_D>)};
     for (const void* f : fns) hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)var_lds_bytes<T>());
+    });
 }
 
 template <typename T>

@@ -12,6 +12,7 @@ initial_theta, bounds)` callable, sklearn's protocol — same bounds, same RNG d
 used only as the container of theta / bounds / fixed flags."""
 from __future__ import annotations
 
+import os
 import warnings
 
 import numpy as np
@@ -73,11 +74,12 @@ def optimize_hyperparameters(gp, c0, ls0, noise0):
     Y = _lib.as_f64(gp.Y, 2, "y")
 
     unpack = _make_unpack(kernel, free, n_ls)
+    ktype = gp._ktype
 
-    def objective(theta):
+    def objective(theta, handle=h):
         c, ls, noise = unpack(theta)
         try:
-            lml, grad = h.lml_objective(X, Y, ls, c, noise, jitter, gp._ktype)     # one C call, no prediction-side model
+            lml, grad = handle.lml_objective(X, Y, ls, c, noise, jitter, ktype)   # one C call, no prediction-side model
         except np.linalg.LinAlgError:                      # _gpr.py:587-590: -inf LML, zero gradient
             return np.inf, np.zeros_like(theta)
         return -lml, -grad[free]
@@ -86,25 +88,80 @@ def optimize_hyperparameters(gp, c0, ls0, noise0):
         value, grad = objective(np.asarray(theta, dtype=np.float64))
         return (value, grad) if eval_gradient else value
 
-    def run(theta_init, bounds):
+    def run(theta_init, bounds, handle=h, deferred=None):
         if callable(gp.optimizer):                          # sklearn/_gpr.py:664-667
             theta_opt, func_min = gp.optimizer(obj_func, theta_init, bounds=bounds)
             return np.asarray(theta_opt, dtype=np.float64), float(func_min)
-        res = scipy.optimize.minimize(objective, theta_init, method="L-BFGS-B", jac=True, bounds=bounds)
+        res = scipy.optimize.minimize(objective, theta_init, args=(handle,), method="L-BFGS-B", jac=True, bounds=bounds)
         if res.status != 0:                                # sklearn's _check_optimize_result("lbfgs", ...)
-            warnings.warn(f"lbfgs failed to converge (status={res.status}): {res.message}")
+            msg = f"lbfgs failed to converge (status={res.status}): {res.message}"
+            if deferred is None:
+                warnings.warn(msg)
+            else:
+                deferred.append(msg)                        # a worker thread: the caller's thread warns (the warnings module's state is global)
         return res.x, res.fun
 
     bounds = kernel.bounds
-    optima = [run(kernel.theta, bounds)]
-    if gp.n_restarts_optimizer > 0:
-        if not np.isfinite(bounds).all():
-            raise ValueError("Multiple optimizer restarts (n_restarts_optimizer>0) requires that all bounds are finite.")
+    n_restarts = gp.n_restarts_optimizer
+    if n_restarts > 0 and not np.isfinite(bounds).all():
+        run(kernel.theta, bounds)                           # sklearn runs the first optimisation before it checks (_gpr.py:311-318)
+        raise ValueError("Multiple optimizer restarts (n_restarts_optimizer>0) requires that all bounds are finite.")
+    workers = _restart_workers(gp, n_restarts, X.shape[0])
+    if workers <= 1:
+        optima = [run(kernel.theta, bounds)]
         rng = np.random.mtrand._rand                       # check_random_state(None): the global RandomState
-        for _ in range(gp.n_restarts_optimizer):
+        for _ in range(n_restarts):
             theta_initial = rng.uniform(bounds[:, 0], bounds[:, 1])
             optima.append(run(theta_initial, bounds))
+    else:
+        optima = _run_concurrently(gp, h, run, kernel.theta, bounds, n_restarts, workers)
     values = [v for _, v in optima]
     best = int(np.argmin(values))
     c, ls, noise = _unpack(kernel, optima[best][0])
     return c, ls, noise, -values[best]
+
+
+def _restart_workers(gp, n_restarts, n_points):
+    """How many L-BFGS-B runs are driven at once.  The runs of sklearn's restart loop are independent: the start points come
+    from the global RNG, which nothing inside a run touches, so drawing them all first gives the same points.  One
+    evaluation of the objective at the reference's sizes (N = 400 .. 2500) is a chain of short launches that leaves most of
+    the 256 CUs idle, so several runs on their own handles (streams, workspaces) overlap on the GPU; every run executes
+    the same kernels on the same data as it would alone, so the optimum found is bit-identical.  Off for a caller's own
+    optimizer (it may use the RNG or not be re-entrant), for large problems (one evaluation fills the GPU, and every handle
+    holds 2 N^2 doubles) and with GPT_OPT_WORKERS=1."""
+    if callable(gp.optimizer) or n_restarts < 1:
+        return 1
+    limit = int(os.environ.get("GPT_OPT_WORKERS", "6"))
+    if n_points > int(os.environ.get("GPT_OPT_WORKERS_MAX_N", "4096")):
+        return 1
+    return max(1, min(limit, n_restarts + 1))
+
+
+def _run_concurrently(gp, h, run, theta0, bounds, n_restarts, workers):
+    import queue
+    from concurrent.futures import ThreadPoolExecutor
+    rng = np.random.mtrand._rand
+    starts = [theta0] + [rng.uniform(bounds[:, 0], bounds[:, 1]) for _ in range(n_restarts)]   # same draws, same order
+    extra = [_lib.Handle(gp.device) for _ in range(workers - 1)]
+    pool = queue.SimpleQueue()
+    for handle in [h] + extra:
+        pool.put(handle)
+
+    def job(theta_init):
+        handle = pool.get()
+        try:
+            msgs = []
+            return run(theta_init, bounds, handle, msgs), msgs
+        finally:
+            pool.put(handle)
+
+    try:
+        with ThreadPoolExecutor(max_workers=workers) as ex:
+            results = list(ex.map(job, starts))
+    finally:
+        for handle in extra:
+            handle.close()
+    for _, msgs in results:
+        for m in msgs:
+            warnings.warn(m)
+    return [out for out, _ in results]

@@ -1131,3 +1131,26 @@ def test_lml_objective_is_fit_plus_gradient_without_a_model():
     with pytest.raises(np.linalg.LinAlgError):
         h.lml_objective(np.vstack([X, X[:5]]), np.vstack([Y, Y[:5]]), np.array([0.1]), 1.0, 0.0, 0.0)
     h.close()
+
+
+def test_concurrent_restart_runs_are_bit_identical_to_sequential_ones(monkeypatch):
+    """The L-BFGS-B runs of sklearn's restart loop are independent (start points from the global RNG, which a run does not
+    touch): driven concurrently on their own handles they must return exactly what the sequential loop returns — same
+    start points, same kernels on the same data — and leave the global RNG in the same state."""
+    from gaussian_process_transportation_amd import GaussianProcess
+    g = load_golden("letterS_2d")
+    rng = np.random.default_rng(4)
+    Xs = rng.uniform(0, 1, (600, 3))
+    Ys = np.column_stack([np.sin(5 * Xs[:, 0]) * Xs[:, 1], np.cos(3 * Xs[:, 2])]) + 0.03 * rng.standard_normal((600, 2))
+    for X, Y, k0, nres in ((g["gp_X"], g["gp_Y"], sk_kernel(10.0, 4 * np.ones(2), 0.01), 5),          # the letter-S transport GP
+                           (Xs, Ys, sk_kernel(1.0, 0.5 * np.ones(3), 0.01), 3)):
+        out = {}
+        for workers in ("1", "6", "3"):
+            monkeypatch.setenv("GPT_OPT_WORKERS", workers)
+            np.random.seed(0)
+            gp = GaussianProcess(kernel=k0, n_restarts_optimizer=nres, verbose=False).fit(X, Y)
+            out[workers] = (np.asarray(gp.gp.kernel_.theta).copy(), gp.gp.log_marginal_likelihood_value_, np.random.uniform())
+        for workers in ("6", "3"):
+            assert np.array_equal(out[workers][0], out["1"][0]) and out[workers][1] == out["1"][1]
+            assert out[workers][2] == out["1"][2]                      # the RNG stream continues from the same state
+    assert_parity(out["1"][0], out["6"][0], 0.0, "theta")
