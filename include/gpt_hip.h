@@ -15,7 +15,8 @@
  *     handle's device (e.g. torch.Tensor.data_ptr()); the library owns every other allocation
  *   - every function returns 0 on success or a negative GPT_E_* code; gpt_last_error() returns
  *     the message of the last failure on the calling thread
- *   - one handle = one fitted model on one GPU; a handle is not thread-safe
+ *   - one handle = one fitted model on one GPU; a handle is not thread-safe, but different handles may be used from
+ *     different threads at the same time (the hyper-parameter search drives its independent restarts that way)
  *   - D (input dims) in 1..8: D <= 3 (the reference's transport problems are 2-D and 3-D) is the tuned layout, D = 4..8
  *     runs on a wider source layout with the same entry points and results (the reference's regressor is
  *     dimension-agnostic; D > 8 is refused with GPT_E_ARG); O (outputs) >= 1; length_scale has 1 (isotropic) or D entries
