@@ -713,8 +713,10 @@ static void launch_gemm_ts(hipStream_t s, const GemmArgs& g) {
 
 // 64-tiles below this many 128-tiles (measured: equal within noise from 2500 up, tools/gpu_fit_ab.sh; a 4096^3 product runs at 64.6 vs 66.3 TFLOP/s)
 static int gemm_tile_threshold() {
-    static int thr = -1;
-    if (thr < 0) { thr = 2500; if (const char* e = getenv("GPT_GEMM_TS64_BELOW")) thr = atoi(e); }
+    static const int thr = [] {                      // (initialised once, thread-safe: handles may be driven from several threads)
+        const char* e = getenv("GPT_GEMM_TS64_BELOW");
+        return e ? atoi(e) : 2500;
+    }();
     return thr;
 }
 
@@ -736,11 +738,10 @@ static void launch_gemm(hipStream_t s, const GemmArgs& g) {
 // panel's steps was tried twice (a second stream with events; update tiles riding in the step launches) and lost
 // both times — profiles/r01_fit_cholesky_ab.log.
 static int potrf_outer_blocks() {
-    static int ob = 0;
-    if (!ob) {
-        ob = 2;
-        if (const char* e = getenv("GPT_POTRF_OB")) { const int v = atoi(e) / NB; if (v >= 1 && v <= 8) ob = v; }
-    }
+    static const int ob = [] {
+        if (const char* e = getenv("GPT_POTRF_OB")) { const int v = atoi(e) / NB; if (v >= 1 && v <= 8) return v; }
+        return 2;
+    }();
     return ob;
 }
 

@@ -583,7 +583,7 @@ def test_device_pointer_api_and_model_handoff():
     h.close(); h2.close()
 
 
-def _two_rank_worker(rank, world, port, q):
+def _two_rank_worker(rank, world, port, q, D=3):
     import os
     import torch
     import torch.distributed as dist
@@ -596,10 +596,10 @@ def _two_rank_worker(rank, world, port, q):
     try:
         rng = np.random.default_rng(11)
         N, M = 700, 5000
-        X = rng.uniform(0, 1, (N, 3)); Y = np.sin(3 * X); Xq = rng.uniform(0, 1, (M, 3))
+        X = rng.uniform(0, 1, (N, D)); Y = np.sin(3 * X[:, :3]); Xq = rng.uniform(0, 1, (M, D))
         h = _lib.Handle(0)
         if rank == 0:
-            h.fit(X, Y, np.array([0.2, 0.25, 0.3]), 0.7, 1e-3, 1e-10)
+            h.fit(X, Y, np.linspace(0.2, 0.3, D) * (1.0 if D <= 3 else 2.5), 0.7, 1e-3, 1e-10)
         nbytes = broadcast_model(h, fitted=(rank == 0), src=0, device=torch.device("cuda", 0))
         a, b = shard_range(M, rank, world)
         out = h.predict_all(Xq[a:b], mean=True, var=True, J=True)
@@ -619,15 +619,17 @@ def _two_rank_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_two_process_model_broadcast_and_sharded_predict():
+@pytest.mark.parametrize("D", [3, 6])
+def test_two_process_model_broadcast_and_sharded_predict(D):
     """Two ranks sharing the one GPU of the test box (gloo, since RCCL needs one GPU per rank): rank 0 fits,
-    broadcast_model ships the blob, both predict their shard; shards must reproduce rank 0's full prediction."""
+    broadcast_model ships the blob, both predict their shard; shards must reproduce rank 0's full prediction.
+    D = 6: the wide source layout travels in the same blob."""
     import os
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29600 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port + 7 * D, q, D)) for r in range(2)]
     for p_ in procs:
         p_.start()
     res = sorted(q.get(timeout=300) for _ in range(2))
