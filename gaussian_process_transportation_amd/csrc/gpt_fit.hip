@@ -694,7 +694,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g, int TM, int TN, int
 struct GemmGrid { int TM, TN, G, fold_tm, nvid; };
 static GemmGrid gemm_grid(const GemmArgs& g, int TS) {
     GemmGrid q{};
-    const int Mmax = g.M > g.M_last ? g.M : g.M_last;
+    // rows to cover: a single batch entry IS the last one.  (Sizing the grid by M there — the top level of the triangular
+    // inverse at N = 2500 is 512 x 2048 with M = 2048 — left 3 of 4 workgroups empty, and since workgroups are dealt to the
+    // CUs in order, the live ones sat four to a CU on a quarter of the chip: 179 us for that product.  A second chunk of
+    // operand prefetch, tried first on the theory that the tile's K loop was latency-bound, changed nothing.)
+    const int Mmax = g.nbatch == 1 ? g.M_last : (g.M > g.M_last ? g.M : g.M_last);
     q.TM = (Mmax + TS - 1) / TS; q.TN = (g.N + TS - 1) / TS;
     if (g.lower_only && g.nbatch == 1 && q.TM == q.TN && q.TM > 1) { q.fold_tm = q.TM; q.TM = (q.fold_tm + 1) / 2; q.TN = q.fold_tm + 1; }
     q.G = (g.nbatch * q.TM + 7) / 8;            // tile rows (over all batch entries) per XCD
@@ -722,7 +726,7 @@ static int gemm_tile_threshold() {
 
 template <bool BT, bool AT = false>
 static void launch_gemm(hipStream_t s, const GemmArgs& g) {
-    const int Mmax = g.M > g.M_last ? g.M : g.M_last;
+    const int Mmax = g.nbatch == 1 ? g.M_last : (g.M > g.M_last ? g.M : g.M_last);
     double tiles = (double)g.nbatch * ((Mmax + 127) / 128) * ((g.N + 127) / 128);
     if (g.lower_only) tiles *= 0.5;
     if (tiles < gemm_tile_threshold()) launch_gemm_ts<BT, AT, 64>(s, g);
