@@ -83,8 +83,7 @@ int var_workgroups() {
     return n[dev].load();
 }
 
-// ncomp: 1 = k* alone; 3 = Jacobian variance alone, D columns per query (D <= 3); 4 / 8 / 16 = var_fused_cols(D)
-static int var_cols_per_query(const KernelParams& p, int ncomp) { return (ncomp == 3) ? p.D : ncomp; }
+static int var_cols_per_query(const KernelParams& p, int ncomp) { return gpt::var_cols_per_query(p.D, ncomp); }   // codes: gpt_common.h
 
 void var_release(VarWorkspace& ws) {
     for (void** pp : {&ws.slab, &ws.vslab, &ws.bscratch, &ws.plan_dev}) { if (*pp) (void)hipFree(*pp); *pp = nullptr; }
@@ -697,7 +696,8 @@ int gpt_predict_all_dev(gpt_handle* h, const void* Xq, int64_t M, void* mean, vo
     if (h->pred_var) {
         // fused: k* and the D derivative columns of a query side by side; 3: Jacobian variance alone (no k* column, D <= 3)
         const int fused = var_fused_cols(h->p.D);
-        const int ncomp = dvar ? fused : (Jvar ? ((var || h->p.D > 3) ? fused : 3) : 1);
+        const int alone = h->p.D <= 3 ? 3 : (h->p.D == 4 ? VAR_NCOMP_DERIV4 : (h->p.D == 8 ? VAR_NCOMP_DERIV8 : fused));
+        const int ncomp = dvar ? fused : (Jvar ? (var ? fused : alone) : 1);
         HIPCHK(var_prepare(h->vws, s, h->p, M, ncomp));
         if (prof) HIPCHK(hipEventRecord(h->pev[2], s));
         launch_var(s, h->p, h->vws, h->dXs(), h->dWf(), Xq, M, ncomp, var, ncomp == 1 ? nullptr : Jvar, ncomp == 1 ? nullptr : dvar, h->dHdr());

@@ -38,6 +38,11 @@ constexpr int MAX_D = 8;
 inline int xs_stride(int D) { return D <= 3 ? 4 : 8; }
 // Columns per query of the fused variance launch (k*, dk_0 .. dk_{D-1}, zero columns up to a power of two).
 inline int var_fused_cols(int D) { return D <= 3 ? 4 : (D <= 7 ? 8 : 16); }
+// `ncomp` codes of var_prepare / launch_var: 1 = k* alone; 3 = Jacobian variance alone, D columns per query (D <= 3);
+// 4 / 8 / 16 = the fused layout (var_fused_cols); and the Jacobian variance alone at D = 4 and D = 8, the two wide
+// dimensions where dropping the k* column halves the columns per query (4 and 8 instead of 8 and 16).
+constexpr int VAR_NCOMP_DERIV4 = 104, VAR_NCOMP_DERIV8 = 108;
+inline int var_cols_per_query(int D, int ncomp) { return ncomp == 3 ? D : (ncomp > 100 ? ncomp - 100 : ncomp); }
 
 // Per-device one-time setup (hipFuncSetAttribute opt-ins, CU counts): a process may hold handles on several devices
 // (gpt_create takes a device), so "done once" has to mean once per device, not once per process.

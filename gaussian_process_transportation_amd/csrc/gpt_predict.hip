@@ -270,7 +270,9 @@ void launch_mean_jac(hipStream_t s, const KernelParams& p, const void* Xs, const
 // DW = 3 is all of the above: D <= 3, source rows of 4 elements, query coordinates in registers.  DW = MAX_D is the
 // wide path for D = 4 .. 8 (rows of 8): only the generating sweep differs — the block's query coordinates sit in LDS
 // (qs[d][query]), distances are coordinate loops — with NCOMP = 1, or NCOMP = 8 / 16: k*, dk_0 .. dk_{D-1} and zero
-// columns up to 8 (D <= 7) or 16 per query, so that a query's columns stay inside one 16-column MFMA tile.
+// columns up to 8 (D <= 7) or 16 per query, so that a query's columns stay inside one 16-column MFMA tile.  KSTAR = false
+// (wide path, NCOMP = 4 for D = 4 and 8 for D = 8): the Jacobian variance alone, dk_0 .. dk_{D-1} without the k* column —
+// half the columns of the fused layout at exactly those two dimensions.
 // ------------------------------------------------------------------------------------------
 // Timing-only ablation builds (results are wrong unless 0): -DGPT_ABL=1 no per-chunk barrier, 2 no A-operand
 // loads, 3 diagonal tile skipped, 4 no B fill (LDS image left as is), 5 no MFMAs.  tools/gpu_ablate.sh,
@@ -285,7 +287,7 @@ template <typename T> constexpr size_t var_lds_bytes() {
     return (El<T>::DIAG_LDS && image > chunks) ? image : chunks;
 }
 
-template <typename T, int NCOMP, bool CROSS, int KT, int DW = 3>
+template <typename T, int NCOMP, bool CROSS, int KT, int DW = 3, bool KSTAR = true>
 __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, const T* __restrict__ Xs,
                                                 const T* __restrict__ Wf, const T* __restrict__ Xq,
                                                 int64_t M, T* __restrict__ slab, T* __restrict__ vslab, T* __restrict__ bscratch) {
@@ -300,8 +302,9 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
     constexpr bool WIDE = DW != 3;
     constexpr int XS = WIDE ? DW : 4;                   // elements per source row
     constexpr int CPQ = NCOMP >= 4 ? NCOMP : 1;         // columns per query when they sit side by side (a power of two)
-    static_assert(!WIDE || (DW == 8 && (NCOMP == 1 || NCOMP == 8 || NCOMP == 16)), "wide path: rows of 8, NCOMP 1 / 8 / 16");
+    static_assert(!WIDE || (DW == 8 && (NCOMP == 1 || NCOMP == 8 || NCOMP == 16 || (!KSTAR && NCOMP == 4))), "wide path: rows of 8, NCOMP 1 / 8 / 16 (4 / 8 without k*)");
     static_assert(WIDE || NCOMP == 1 || NCOMP == 3 || NCOMP == 4, "D <= 3: NCOMP 1 / 3 / 4");
+    static_assert(KSTAR || (WIDE && !CROSS && (NCOMP == 4 || NCOMP == 8)), "no k* column: wide path, Jacobian variance alone");
     __shared__ T red[2][8][VAR_COLS];
     __shared__ double Tt[256];
     __shared__ T qs[WIDE ? DW : 1][VAR_COLS];           // wide path: scaled coordinates of this block's queries, [d][query]
@@ -317,7 +320,7 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
     // NCOMP=4: column = 4 query + comp, comp = lc & 3 in every tile: b = kv * (cbv + sum_d cd[d] * d'_d).
     // NCOMP=3 (Jacobian variance alone, no k* column): column = D query + d, D columns per query; for D = 3 the d of a
     // lane's column changes from tile to tile and from block to block (16 = 64 = 1 mod 3), selected in `produce`.
-    const int comp = (CPQ > 1) ? (lc & (CPQ - 1)) : 0;
+    const int comp = (CPQ > 1) ? (lc & (CPQ - 1)) + (KSTAR ? 0 : 1) : 0;      // 0: the k* column, 1 + d: dk_d
     const T cbv = (comp == 0) ? (T)1 : (T)0;
     T cd[3];
 #pragma unroll
@@ -746,7 +749,7 @@ __global__ __launch_bounds__(512) void k_var_combine(VarPlanDev pl, const T* __r
 
 // Adds the partial sums of a (column block, task) in slot order and turns them into outputs:
 // var (M, ntask), Jvar (M, ntask, D), dvar (D, M) (ntask = 1 only).
-template <typename T, int NCOMP>
+template <typename T, int NCOMP, bool KSTAR = true>
 __global__ __launch_bounds__(64) void k_var_finalize(KernelParams p, VarPlanDev pl, const T* __restrict__ slab, int64_t M,
                                                      const double* __restrict__ hdr, T* __restrict__ var,
                                                      T* __restrict__ Jvar, T* __restrict__ dvar) {
@@ -755,7 +758,7 @@ __global__ __launch_bounds__(64) void k_var_finalize(KernelParams p, VarPlanDev 
     const int D = p.D, NT = pl.ntask;
     const int64_t col = cb * VAR_COLS + cl;
     const int64_t m = (NCOMP == 1) ? col : ((NCOMP >= 4) ? (col / NCOMP) : (col / D));
-    const int cmp = (NCOMP == 1) ? 0 : ((NCOMP >= 4) ? (int)(col & (NCOMP - 1)) : 1 + (int)(col % D));
+    const int cmp = (NCOMP == 1) ? 0 : ((NCOMP >= 4) ? (int)(col & (NCOMP - 1)) + (KSTAR ? 0 : 1) : 1 + (int)(col % D));
     for (int task = 0; task < NT; ++task) {
         T s2 = (T)0, cr = (T)0;
         int s_begin, s_end;
@@ -796,7 +799,8 @@ static void var_kernel_setup() {
                          reinterpret_cast<const void*>(k_var<T, 1, false, KT_RBF, MAX_D>), reinterpret_cast<const void*>(k_var<T, 1, false, KT_MATERN12, MAX_D>),
                          reinterpret_cast<const void*>(k_var<T, 1, false, KT_MATERN32, MAX_D>), reinterpret_cast<const void*>(k_var<T, 1, false, KT_MATERN52, MAX_D>),
                          reinterpret_cast<const void*>(k_var<T, 8, true, KT_RBF, MAX_D>), reinterpret_cast<const void*>(k_var<T, 8, false, KT_RBF, MAX_D>),
-                         reinterpret_cast<const void*>(k_var<T, 16, true, KT_RBF, MAX_D>), reinterpret_cast<const void*>(k_var<T, 16, false, KT_RBF, MAX_D>)};
+                         reinterpret_cast<const void*>(k_var<T, 16, true, KT_RBF, MAX_D>), reinterpret_cast<const void*>(k_var<T, 16, false, KT_RBF, MAX_D>),
+                         reinterpret_cast<const void*>(k_var<T, 4, false, KT_RBF, MAX_D, false>), reinterpret_cast<const void*>(k_var<T, 8, false, KT_RBF, MAX_D, false>)};
     for (const void* f : fns) hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)var_lds_bytes<T>());
     });
 }
@@ -821,7 +825,11 @@ static void launch_var_t(hipStream_t s, const KernelParams& p, const VarWorkspac
             default: GPT_KVAR(1, false, KT_RBF, DW_);                    \
         }
     const bool cross = ncomp >= 4 && dvar != nullptr;
-    if (ncomp == 1) {
+    if (ncomp == VAR_NCOMP_DERIV4) {          // D = 4, Jacobian variance alone: dk_0 .. dk_3
+        hipLaunchKernelGGL((k_var<T, 4, false, KT_RBF, MAX_D, false>), grid, dim3(512), lds, s, p, pl, Xs, Wf, Xq, M, slab, vslab, bscr);
+    } else if (ncomp == VAR_NCOMP_DERIV8) {   // D = 8
+        hipLaunchKernelGGL((k_var<T, 8, false, KT_RBF, MAX_D, false>), grid, dim3(512), lds, s, p, pl, Xs, Wf, Xq, M, slab, vslab, bscr);
+    } else if (ncomp == 1) {
         if (wide) { GPT_KVAR1(MAX_D) } else { GPT_KVAR1(3) }
     } else if (ncomp == 3) {      // Jacobian variance alone: D columns per query (D <= 3)
         GPT_KVAR(3, false, KT_RBF, 3);
@@ -844,6 +852,8 @@ static void launch_var_t(hipStream_t s, const KernelParams& p, const VarWorkspac
         else hipLaunchKernelGGL((k_var_combine<T, true, 16>), cgrid, dim3(512), 0, s, pl, vslab, slab);
     }
     switch (ncomp) {
+        case VAR_NCOMP_DERIV4: hipLaunchKernelGGL((k_var_finalize<T, 4, false>), fgrid, dim3(64), 0, s, p, pl, slab, M, hdr, var, Jvar, dvar); break;
+        case VAR_NCOMP_DERIV8: hipLaunchKernelGGL((k_var_finalize<T, 8, false>), fgrid, dim3(64), 0, s, p, pl, slab, M, hdr, var, Jvar, dvar); break;
         case 1: hipLaunchKernelGGL((k_var_finalize<T, 1>), fgrid, dim3(64), 0, s, p, pl, slab, M, hdr, var, Jvar, dvar); break;
         case 3: hipLaunchKernelGGL((k_var_finalize<T, 3>), fgrid, dim3(64), 0, s, p, pl, slab, M, hdr, var, Jvar, dvar); break;
         case 4: hipLaunchKernelGGL((k_var_finalize<T, 4>), fgrid, dim3(64), 0, s, p, pl, slab, M, hdr, var, Jvar, dvar); break;

@@ -90,8 +90,7 @@ void launch_var(hipStream_t, const KernelParams& p, const VarWorkspace& ws, cons
             const int b = pl.d.fin[2 * (c * p.ntask + t)], en = pl.d.fin[2 * (c * p.ntask + t) + 1];
             touch_r(static_cast<unsigned char*>(ws.slab) + (size_t)b * VAR_SLOT * e, (size_t)(en - b) * VAR_SLOT * e);
         }
-    const int cpq = ncomp == 3 ? p.D : ncomp;
-    (void)cpq;
+    (void)var_cols_per_query(p.D, ncomp);
     touch_w(var, (size_t)M * p.ntask * e); touch_w(Jvar, (size_t)M * p.ntask * p.D * e); touch_w(dvar, (size_t)M * p.D * e);
 }
 

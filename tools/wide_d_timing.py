@@ -28,19 +28,22 @@ for dtype, tname, peak in ((_lib.GPT_F64, "fp64", 78.6e12), (_lib.GPT_F32, "fp32
         mean = torch.empty((M, 3), dtype=tt, device="cuda"); var = torch.empty(M, dtype=tt, device="cuda")
         J = torch.empty((M, 3, D), dtype=tt, device="cuda"); Jv = torch.empty((M, D), dtype=tt, device="cuda")
         h.set_profiling(True)
-        for mode, jv in (("J", 0), ("JVAR", Jv.data_ptr())):
-            h.predict_all_dev(xq.data_ptr(), M, mean.data_ptr(), var.data_ptr(), J.data_ptr(), jv, 0)
+        # J: mean + variance + Jacobian; JVAR: the same + Jacobian variance (fused columns); JV-ALONE: mean + Jacobian +
+        # Jacobian variance without the variance (what the reference's transport_velocity asks for)
+        for mode, vp, jv in (("J", var.data_ptr(), 0), ("JVAR", var.data_ptr(), Jv.data_ptr()), ("JV-ALONE", 0, Jv.data_ptr())):
+            h.predict_all_dev(xq.data_ptr(), M, mean.data_ptr(), vp, J.data_ptr(), jv, 0)
             h.synchronize()
             reps = 3
             t0 = time.perf_counter()
             for _ in range(reps):
-                h.predict_all_dev(xq.data_ptr(), M, mean.data_ptr(), var.data_ptr(), J.data_ptr(), jv, 0)
+                h.predict_all_dev(xq.data_ptr(), M, mean.data_ptr(), vp, J.data_ptr(), jv, 0)
             h.synchronize()
             dt = (time.perf_counter() - t0) / reps
             tm = h.predict_timings()
             t_mj, t_var = tm["mean_jac_ms"], tm["var_ms"]
-            cols = 1 if not jv else (4 if D <= 3 else (8 if D <= 7 else 16))
-            useful = 1 if not jv else 1 + D
+            fused = 4 if D <= 3 else (8 if D <= 7 else 16)
+            cols = 1 if not jv else (fused if vp else (D if D <= 4 or D == 8 else fused))
+            useful = 1 if not jv else (1 + D if vp else D)
             NP = (N + 511) // 512 * 512
             flops = M * cols * (NP * (NP + 512.0))          # block lower triangle incl. diagonal tiles, 2 flop per MAC
             print(f"{tname} D={D} {mode}: {M/dt:.0f} q/s ({dt*1e3:.1f} ms; mean+J {t_mj:.1f} ms, k_var {t_var:.1f} ms = "
