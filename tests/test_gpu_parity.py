@@ -242,6 +242,30 @@ def test_input_dimension_beyond_three_vs_oracle(N, M, D, O, ls):
     h.close()
 
 
+def test_transportation_in_five_dimensions_vs_oracle():
+    """The whole transport flow (affine pre-alignment, delta-map GP, transported positions / std / velocities / velocity
+    variance: policy_transportation.py:16-59) on a 5-D state, against the CPU restatement of the same algebra."""
+    from oracle import gp_oracle as orc
+    rng = np.random.default_rng(8)
+    D, N, M = 5, 300, 200
+    src = rng.uniform(-1, 1, (N, D))
+    Q, _ = np.linalg.qr(rng.standard_normal((D, D)))
+    if np.linalg.det(Q) < 0:
+        Q[:, 0] = -Q[:, 0]
+    tgt = src @ Q.T + 0.3 + 0.1 * np.sin(2 * src) + 0.005 * rng.standard_normal((N, D))
+    traj = rng.uniform(-0.9, 0.9, (M, D))
+    vel = 0.05 * rng.standard_normal((M, D))
+    c, ls, noise = 0.5, np.array([0.8, 1.0, 0.7, 0.9, 1.1]), 1e-3
+    g = dict(constant_value=c, length_scale=ls, noise_level=noise, source=src, target=tgt, demo=traj, delta=vel)
+    tr = _transport(g)
+    want = orc.transport_oracle(orc.GaussianProcessOracle(c, ls, noise), src, tgt, traj, vel)
+    assert_parity(tr.method.affine_transform.rotation_matrix, want["rotation"], 1e-10, "rotation")
+    assert_parity(tr.training_traj, want["traj"], RTOL, "traj")
+    assert_parity(tr.std, want["std"], RTOL, "std")
+    assert_parity(tr.training_delta, want["vel"], RTOL, "vel")
+    assert_parity(tr.var_vel_transported, want["var_vel"], RTOL, "var_vel")
+
+
 def test_gaussian_process_class_in_six_dimensions_matches_sklearn_after_optimisation():
     """GaussianProcess (the reference's class surface) on a 6-D input with the optimizer on: the fitted hyper-parameters
     and the log-marginal likelihood against scikit-learn's own GaussianProcessRegressor run from the same start with the
