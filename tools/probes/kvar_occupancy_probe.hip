@@ -16,7 +16,8 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 
 struct AF { d2 lo, hi; };
 
-template <int WAVES, int R, int UNR = 8>
+// ABL (bit mask, timing only): 1 = A fragments not reloaded, 2 = B fragments not re-read from LDS, 4 = no barrier
+template <int WAVES, int R, int UNR = 8, int ABL = 0, int PF = 2>
 __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void k_probe(const double* __restrict__ A, double* __restrict__ out, int ksteps, int passes) {
     extern __shared__ __attribute__((aligned(16))) double Bs[];          // [32 k-steps][64 lanes][4]
     const int lane = threadIdx.x & 63;
@@ -35,9 +36,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void k_probe(const 
     const d2* base = reinterpret_cast<const d2*>(A) + (size_t)w * R * 128 + lane;
     auto lda = [&](AF& a, size_t s, int r) { const d2* p = base + s * STEP + (size_t)r * 128; a.lo = p[0]; a.hi = p[64]; };
     for (int pass = 0; pass < passes; ++pass) {
-        AF ring[2][R];
+        AF ring[PF][R];                                                  // A fragments of the next PF k-steps (PF divides UNR)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < PF; ++i)
 #pragma unroll
             for (int r = 0; r < R; ++r) lda(ring[i][r], i, r);
         for (int k0 = 0; k0 < ksteps; k0 += 32) {
@@ -46,12 +47,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void k_probe(const 
             for (int su = 0; su < UNR; ++su) {
                 const int s = s8 + su;
                 const int k4 = k0 + s;
-                const d4 b = *reinterpret_cast<const d4*>(&Bs[(s * 64 + lane) * 4]);
+                const d4 b = *reinterpret_cast<const d4*>(&Bs[(((ABL & 2) ? 0 : s) * 64 + lane) * 4]);
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    const AF a = ring[s & 1][r];
-                    const size_t sn = (k4 + 2 < ksteps) ? (size_t)(k4 + 2) : (size_t)(ksteps - 1);
-                    lda(ring[s & 1][r], sn, r);
+                    const AF a = ring[su % PF][r];
+                    const size_t sn = (k4 + PF < ksteps) ? (size_t)(k4 + PF) : (size_t)(ksteps - 1);
+                    if (!(ABL & 1)) lda(ring[su % PF][r], sn, r);
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         acc[r][0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.lo[0], b[t], acc[r][0][t], 0, 0, 0);
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void k_probe(const 
                 }
             }
           }
-            __syncthreads();
+            if (!(ABL & 4)) __syncthreads();
         }
     }
     double sum = 0;
@@ -75,21 +76,23 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void k_probe(const 
     out[(size_t)blockIdx.x * WAVES * 64 + threadIdx.x] = sum;
 }
 
-template <int WAVES, int R, int UNR = 8>
+template <int WAVES, int R, int UNR = 8, int ABL = 0, int PF = 2>
 void run(const double* A, double* out, int blocks, int ksteps, int passes, size_t lds) {
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_probe<WAVES, R, UNR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_probe<WAVES, R, UNR, ABL, PF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    hipLaunchKernelGGL((k_probe<WAVES, R, UNR>), dim3(blocks), dim3(WAVES * 64), lds, 0, A, out, ksteps, 1);
+    hipLaunchKernelGGL((k_probe<WAVES, R, UNR, ABL, PF>), dim3(blocks), dim3(WAVES * 64), lds, 0, A, out, ksteps, 1);
     CK(hipDeviceSynchronize());
     float best = 1e30f;
     for (int rep = 0; rep < 3; ++rep) {
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL((k_probe<WAVES, R, UNR>), dim3(blocks), dim3(WAVES * 64), lds, 0, A, out, ksteps, passes);
+        hipLaunchKernelGGL((k_probe<WAVES, R, UNR, ABL, PF>), dim3(blocks), dim3(WAVES * 64), lds, 0, A, out, ksteps, passes);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
     }
-    hipFuncAttributes fa; CK(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_probe<WAVES, R, UNR>)));
+    hipFuncAttributes fa; CK(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_probe<WAVES, R, UNR, ABL, PF>)));
     const double flops = 2.0 * 16 * 16 * 4 * 16.0 * R * WAVES * (double)ksteps * passes * blocks;
+    if (ABL) printf("  [ablation %d%s%s%s] ", ABL, (ABL & 1) ? " no A loads" : "", (ABL & 2) ? " no B reads" : "", (ABL & 4) ? " no barrier" : "");
+    if (PF != 2) printf("  [A fragments %d steps ahead] ", PF);
     printf("waves/WG %d (%d per SIMD), row groups per wave %d (%4d rows per B pass), unrolled by %d: %8.3f ms  %6.2f TFLOP/s   [%d registers, %zu B of scratch per lane]\n",
            WAVES, WAVES / 4, R, WAVES * R * 64, UNR, best, flops / best * 1e-9, fa.numRegs, fa.localSizeBytes);
 }
@@ -109,6 +112,19 @@ int main(int argc, char** argv) {
     run<4, 3>(A, out, cus, ksteps, passes8 * 2 / 3, lds);
     run<4, 3, 2>(A, out, cus, ksteps, passes8 * 2 / 3, lds);
     run<4, 1>(A, out, cus, ksteps, passes8 * 2, lds);
+    run<8, 1>(A, out, cus, ksteps, passes8, lds);
+    // where the shipped shape's steady state loses its 5 % against the bare MFMA rate (77.7 TFLOP/s, mfma_f64_probe)
+    run<8, 1, 8, 1>(A, out, cus, ksteps, passes8, lds);
+    run<8, 1, 8, 2>(A, out, cus, ksteps, passes8, lds);
+    run<8, 1, 8, 4>(A, out, cus, ksteps, passes8, lds);
+    run<8, 1, 8, 3>(A, out, cus, ksteps, passes8, lds);
+    run<8, 1, 8, 7>(A, out, cus, ksteps, passes8, lds);
+    run<8, 1>(A, out, cus, ksteps, passes8, lds);
+    // how far ahead the A fragments have to be requested
+    run<8, 1, 8, 0, 1>(A, out, cus, ksteps, passes8, lds);
+    run<8, 1, 8, 0, 4>(A, out, cus, ksteps, passes8, lds);
+    run<8, 1, 8, 0, 8>(A, out, cus, ksteps, passes8, lds);
+    run<4, 2, 8, 0, 4>(A, out, cus, ksteps, passes8, lds);
     run<8, 1>(A, out, cus, ksteps, passes8, lds);
     return 0;
 }
