@@ -83,6 +83,23 @@ def cpu_baseline(N, D, O, sample, jvar):
     return out
 
 
+def visible_device_shortfall(gpus):
+    """A device restriction already in the environment (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES,
+    which the ROCm runtime also honours) is kept: rank r uses device r OF THE VISIBLE SET (the children inherit the
+    variables unchanged and select `LOCAL_RANK` inside them).  Returns a message when a variable lists fewer devices than
+    --gpus — known from the strings alone, before any process is started or any GPU is touched — else None."""
+    for name in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        val = os.environ.get(name)
+        if val is None:
+            continue
+        ids = [t for t in val.replace(" ", "").split(",") if t != ""]
+        if "-1" in ids:                                   # the runtimes stop reading the list at -1
+            ids = ids[:ids.index("-1")]
+        if len(ids) < gpus:
+            return f"--gpus {gpus} but {name}={val!r} leaves {len(ids)} device(s) visible"
+    return None
+
+
 def launch_ranks(args, argv):
     """`python bench.py --gpus N` with N > 1 and no torch.distributed environment: this process becomes a pure
     launcher.  It has not imported torch, loaded libgpt_hip.so or made any HIP call (and never does): it starts
@@ -90,6 +107,11 @@ def launch_ranks(args, argv):
     print (rank 0's JSON line on stdout, everything else on stderr) and exits with the worst return code."""
     import socket
     import subprocess
+    # (a --dry-run uses no device: the check is rehearsed there only on request, GPT_BENCH_DRY_CHECK_DEVICES=1)
+    short = visible_device_shortfall(args.gpus) if (not args.dry_run or os.environ.get("GPT_BENCH_DRY_CHECK_DEVICES") == "1") else None
+    if short:
+        print(f"bench launcher: {short}", file=sys.stderr)
+        return 2
     with socket.socket() as sk:                      # a free rendezvous port on the loopback interface
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -175,6 +197,8 @@ def main():
                     help="exact: the headline metric (BASELINE configs[2]/[3]); svgp: configs[4], fp32 SVGP-MIMO path")
     ap.add_argument("--inducing", type=int, default=2048, help="inducing points of --config svgp")
     ap.add_argument("--dry-run", action="store_true", help="multi-rank skeleton over gloo on the CPU, no GPU work")
+    ap.add_argument("--no-secondary", dest="secondary", action="store_false",
+                    help="skip the `secondary` records (mode J+Jvar, configs[1], configs[4]) measured after the headline on one GPU")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -199,6 +223,13 @@ def init_ranks(args):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    short = visible_device_shortfall(args.gpus)
+    if short:
+        raise SystemExit(f"rank {rank}: {short}")
+    n_visible = torch.cuda.device_count()                  # (counting devices does not initialise the GPU)
+    if local_rank >= n_visible or args.gpus > n_visible:
+        raise SystemExit(f"rank {rank}: --gpus {args.gpus}, LOCAL_RANK {local_rank}, but only {n_visible} HIP device(s) are visible "
+                         "(HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES?)")
     _lib.require_gpu()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -237,22 +268,24 @@ def broadcast_fitted(torch, dist, h, rank, dev, use_dist):
     return (time.perf_counter() - t0) * 1e3, nbytes
 
 
-def timed_steps(torch, dist, h, step, args, dev, use_dist):
+def timed_steps(torch, dist, h, step, args, dev, use_dist, steps=None, warmup=None):
     """W warm-up steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks.  The
     dominant kernel's duration is read per step from the library's hipEvents on the launch stream."""
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
     def sync_all():
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     sync_all()
     h.set_profiling(True)
     var_ms, mj_ms = [], []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
         t = h.predict_timings()          # waits for this step's events only (the next launch follows at once)
         var_ms.append(t["var_ms"]); mj_ms.append(t["mean_jac_ms"])
@@ -283,6 +316,79 @@ def pmc_traffic(key, n_source, queries):
     return None, None
 
 
+def exact_buffers(torch, dev, M, D, O, jvar, seed):
+    xq_host = np.random.default_rng(seed).uniform(-0.1, 1.1, (M, D))
+    xq = torch.from_numpy(xq_host).to(dev)
+    mean = torch.empty((M, O), dtype=torch.float64, device=dev)
+    var = torch.empty((M,), dtype=torch.float64, device=dev)
+    J = torch.empty((M, O, D), dtype=torch.float64, device=dev)
+    Jvar = torch.empty((M, D), dtype=torch.float64, device=dev) if jvar else None
+    return xq, mean, var, J, Jvar
+
+
+def measure_exact(ctx, args, N, M, jvar, steps, warmup, c=0.1, noise=1e-4):
+    """K timed steps of the fused predict pass of a fitted exact-GP handle over M resident queries; returns the record of
+    this mode (value over all ranks, dominant-kernel duration from the library's hipEvents, roofline fields)."""
+    torch, dist, h, rank, world, dev, use_dist = ctx
+    D = O = 3
+    xq, mean, var, J, Jvar = exact_buffers(torch, dev, M, D, O, jvar, 1 + rank)
+    h.reserve(M, jvar)               # library scratch of the timed calls: allocated here, not inside the first step
+
+    def step():
+        h.predict_all_dev(xq.data_ptr(), M, mean.data_ptr(), var.data_ptr(), J.data_ptr(),
+                          Jvar.data_ptr() if Jvar is not None else 0, 0)
+
+    elapsed, kern_ms, mj_ms = timed_steps(torch, dist, h, step, args, dev, use_dist, steps, warmup)
+    # ---- sanity of the timed outputs (finite, variance within [0, c+noise])
+    ok = bool(torch.isfinite(mean).all() and torch.isfinite(J).all() and torch.isfinite(var).all()
+              and float(var.min()) >= 0.0 and float(var.max()) <= c + noise + 1e-12
+              and (Jvar is None or bool(torch.isfinite(Jvar).all())))
+    if not ok and not os.environ.get("GPT_BENCH_ABLATE"):     # timing-only ablation builds compute wrong values
+        raise SystemExit("bench: non-finite or out-of-range outputs")
+    kflops = var_kernel_flops_per_query(N, D, jvar) * M
+    achieved = kflops / (kern_ms * 1e-3) / 1e12
+    traffic, traffic_source = pmc_traffic("jvar" if jvar else "j", N, M)
+    return {"value": world * M * steps / elapsed, "elapsed_s": elapsed, "ms_per_step": elapsed / steps * 1e3, "steps": steps,
+            "warmup": warmup, "flops_per_query": flops_per_query(N, D, O, jvar),
+            "roofline": {"bound": "mfma", "kernel": "k_var (variance / Jacobian-variance triangular MFMA GEMM)",
+                         "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel_ms": kern_ms, "mean_jac_kernel_ms": mj_ms}}
+
+
+def measure_config1(_lib, steps=5):
+    """BASELINE configs[1]: N = 1024 sources, M = 50 000 queries, fit + predict(mean, std), no Jacobian, fp64 — as a caller
+    of the drop-in sees it: numpy in, numpy out through the host-pointer entry points (PCIe inclusive)."""
+    N, M, D = 1024, 50_000, 3
+    X, Y = synthetic_sources(N, D)
+    Xq = np.random.default_rng(1).uniform(-0.1, 1.1, (M, D))
+    ls = np.array([0.1] * D)
+    h = _lib.Handle(0)
+    h.fit(X, Y, ls, 0.1, 1e-4, 1e-10)
+    h.predict_all(Xq, mean=True, var=True)
+    fit_s, pred_s, kern = [], [], []
+    h.set_profiling(True)
+    for _ in range(steps):
+        t0 = time.perf_counter(); h.fit(X, Y, ls, 0.1, 1e-4, 1e-10); fit_s.append(time.perf_counter() - t0)
+        t0 = time.perf_counter(); out = h.predict_all(Xq, mean=True, var=True); pred_s.append(time.perf_counter() - t0)
+        kern.append(h.predict_timings()["var_ms"])
+    h.set_profiling(False)
+    fit_phases = h.fit_timings()
+    ok = bool(np.isfinite(out["mean"]).all() and out["var"].min() >= 0.0 and out["var"].max() <= 0.1 + 1e-4 + 1e-12)
+    h.close()
+    if not ok:
+        raise SystemExit("bench (configs[1]): non-finite or out-of-range outputs")
+    fit_ms, pred_ms, kern_ms = float(np.median(fit_s)) * 1e3, float(np.median(pred_s)) * 1e3, float(np.median(kern))
+    kflops = (N * N + 2 * N + N * (3 * D + 1)) * M
+    achieved = kflops / (kern_ms * 1e-3) / 1e12
+    return {"workload": "BASELINE configs[1]: N=1024 source pts, M=50000 queries, fit + predict(mean, std), no Jacobian, fp64, "
+                        "numpy in -> numpy out (host-pointer API, PCIe inclusive)",
+            "value": M / (pred_ms * 1e-3), "unit": "predictions/s (predict mean+std, host to host)", "ms_per_step": pred_ms,
+            "fit_ms": fit_ms, "fit_plus_predict_ms": fit_ms + pred_ms, "fit_phases_ms": fit_phases, "steps": steps, "dtype": "f64",
+            "roofline": {"bound": "mfma", "kernel": "k_var<double,1>", "kernel_ms": kern_ms, "achieved": achieved,
+                         "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_MFMA_TFLOPS}}
+
+
 def run_exact(args):
     torch, dist, h, rank, world, dev, use_dist, ranks_seen = init_ranks(args)
     N, D, O, M = args.n_source, 3, 3, args.queries
@@ -299,55 +405,54 @@ def run_exact(args):
         fit_timings = h.fit_timings()
     bcast_ms, bcast_bytes = broadcast_fitted(torch, dist, h, rank, dev, use_dist)
 
-    # ---- this rank's query shard, resident in HBM
-    xq_host = np.random.default_rng(1 + rank).uniform(-0.1, 1.1, (M, D))
-    xq = torch.from_numpy(xq_host).to(dev)
-    mean = torch.empty((M, O), dtype=torch.float64, device=dev)
-    var = torch.empty((M,), dtype=torch.float64, device=dev)
-    J = torch.empty((M, O, D), dtype=torch.float64, device=dev)
-    Jvar = torch.empty((M, D), dtype=torch.float64, device=dev) if args.jvar else None
+    ctx = (torch, dist, h, rank, world, dev, use_dist)
+    rec = measure_exact(ctx, args, N, M, args.jvar, args.steps, args.warmup)
 
-    h.reserve(M, args.jvar)          # library scratch of the timed calls: allocated here, not inside the first step
-
-    def step():
-        h.predict_all_dev(xq.data_ptr(), M, mean.data_ptr(), var.data_ptr(), J.data_ptr(),
-                          Jvar.data_ptr() if Jvar is not None else 0, 0)
-
-    elapsed, kern_ms, mj_ms = timed_steps(torch, dist, h, step, args, dev, use_dist)
-
-    # ---- sanity of the timed outputs (finite, variance within [0, c+noise])
-    ok = bool(torch.isfinite(mean).all() and torch.isfinite(J).all() and torch.isfinite(var).all()
-              and float(var.min()) >= 0.0 and float(var.max()) <= 0.1 + 1e-4 + 1e-12)
-    if not ok and not os.environ.get("GPT_BENCH_ABLATE"):     # timing-only ablation builds compute wrong values
-        raise SystemExit("bench: non-finite or out-of-range outputs")
+    # ---- the other single-GPU configurations, after the headline's timed region, same process (N = 1 only)
+    secondary = None
+    if world == 1 and not use_dist and args.secondary:
+        from gaussian_process_transportation_amd import _lib
+        secondary = {}
+        if not args.jvar:
+            r = measure_exact(ctx, args, N, M, True, 5, 1)
+            secondary["mode_J+Jvar"] = {"workload": f"N={N}, M={M}, mean+var+Jacobian+Jacobian variance (4 columns per query), fp64, resident",
+                                        "value": r["value"], "unit": "predictions/s", "ms_per_step": r["ms_per_step"], "steps": 5,
+                                        "dtype": "f64", "roofline": r["roofline"]}
+        torch.cuda.synchronize()
+        secondary["configs[1]"] = measure_config1(_lib)
+        sv = measure_svgp((torch, dist, None, rank, world, dev, use_dist), args, args.inducing, 1_000_000, 10, 1)
+        secondary["configs[4]"] = {"workload": sv["workload"], "value": sv["value"], "unit": "predictions/s",
+                                   "ms_per_step": sv["ms_per_step"], "steps": 10, "dtype": "f32", "fit_ms": sv["fit_ms"],
+                                   "roofline": sv["roofline"]}
 
     if rank == 0:
-        value = world * M * args.steps / elapsed
-        kflops = var_kernel_flops_per_query(N, D, args.jvar) * M
-        achieved = kflops / (kern_ms * 1e-3) / 1e12
-        traffic, traffic_source = pmc_traffic("jvar" if args.jvar else "j", N, M)
         out = {
             "metric": "posterior (mean+var+Jacobian) preds/sec, N=8192 source pts, 3-D fp64",
-            "value": value, "unit": "predictions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "value": rec["value"], "unit": "predictions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"N={N} source pts, M={M} queries per GPU per step, D=O=3, "
                                    f"mean+var+Jacobian{'+Jacobian variance' if args.jvar else ''}, RBF GP, fp64"
                                    + (f"; {world}x{M} queries sharded, one RCCL broadcast of the factor" if world > 1 else ""),
                        "n_source": N, "queries_per_gpu": M, "mode": "J+Jvar" if args.jvar else "J"},
-            "flops_per_query": flops_per_query(N, D, O, args.jvar),
-            "achieved_tflops_whole_path": value * flops_per_query(N, D, O, args.jvar) / 1e12 / world,
-            "roofline": {"bound": "mfma", "kernel": "k_var (variance / Jacobian-variance triangular MFMA GEMM)",
-                         "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel_ms": kern_ms, "mean_jac_kernel_ms": mj_ms},
+            "flops_per_query": rec["flops_per_query"],
+            "achieved_tflops_whole_path": rec["value"] * rec["flops_per_query"] / 1e12 / world,
+            "roofline": rec["roofline"],
             "fit_ms": fit_ms, "fit_phases_ms": fit_timings, "bcast_ms": bcast_ms, "bcast_bytes": bcast_bytes,
             "ranks_seen": ranks_seen,
         }
+        if use_dist and bcast_ms is not None:
+            # "include broadcast time in cfg4's number" — `value` times the K steps only (a model is broadcast
+            # once per fit, not per batch); value_incl_bcast charges the one broadcast to these K steps
+            out["value_incl_bcast"] = world * M * args.steps / (rec["elapsed_s"] + bcast_ms * 1e-3)
+            out["value_note"] = ("value = queries of all ranks / time of the K timed steps (max over ranks), the model broadcast "
+                                 "excluded; value_incl_bcast = the same queries / (that time + bcast_ms)")
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(N, D, O, args.cpu_sample, args.jvar)
         else:
             out["cpu_baseline"] = None
+        if secondary is not None:
+            out["secondary"] = secondary
         print(json.dumps(out), flush=True)
     h.close()
     if use_dist:
@@ -391,9 +496,54 @@ def svgp_cpu_baseline(Z, sample):
                       f"numpy BLAS threads; conversion (3 fp32 inverses) took {t_fit:.2f} s", "fit_s": t_fit}
 
 
+def measure_svgp(ctx, args, Z, M, steps, warmup, h=None, bcast=None):
+    """BASELINE configs[4]: SVGP-MIMO derivative path, Z inducing points, T = D = 3, M resident queries, fp32.
+    A step = mean (M,T), variance (M,T), Jacobian (M,T,D) and Jacobian variance (M,T,D) of one batch.  Fits the model
+    on a handle of its own unless one is passed in (already fitted / broadcast)."""
+    from gaussian_process_transportation_amd import _lib
+    torch, dist, _, rank, world, dev, use_dist = ctx
+    T, D = 3, 3
+    fit_ms = None
+    own = h is None
+    if own:
+        h = _lib.Handle(dev.index or 0)
+        h.set_stream(torch.cuda.current_stream().cuda_stream)
+        Zp, Sigma, y, osc, ls = svgp_synthetic_model(Z, T, D)
+        h.fit_svgp(Zp, y, Sigma, ls, osc, dtype=_lib.GPT_F32)
+        t0 = time.perf_counter()
+        h.fit_svgp(Zp, y, Sigma, ls, osc, dtype=_lib.GPT_F32)
+        fit_ms = (time.perf_counter() - t0) * 1e3
+    xq = torch.from_numpy(np.random.default_rng(1 + rank).uniform(-0.1, 1.1, (M, D)).astype(np.float32)).to(dev)
+    f32 = torch.float32
+    mean = torch.empty((M, T), dtype=f32, device=dev); var = torch.empty((M, T), dtype=f32, device=dev)
+    J = torch.empty((M, T, D), dtype=f32, device=dev); Jvar = torch.empty((M, T, D), dtype=f32, device=dev)
+    h.reserve(M, True)
+
+    def step():
+        h.predict_all_dev(xq.data_ptr(), M, mean.data_ptr(), var.data_ptr(), J.data_ptr(), Jvar.data_ptr(), 0)
+
+    elapsed, kern_ms, mj_ms = timed_steps(torch, dist, h, step, args, dev, use_dist, steps, warmup)
+    ok = bool(torch.isfinite(mean).all() and torch.isfinite(J).all() and torch.isfinite(var).all() and torch.isfinite(Jvar).all()
+              and float(var.min()) >= 0.0 and float(var.max()) <= 1.0 + 1e-5)
+    if not ok and not os.environ.get("GPT_BENCH_ABLATE"):     # timing-only ablation builds compute wrong values
+        raise SystemExit("bench (svgp): non-finite or out-of-range outputs")
+    if own:
+        h.close()
+    fq, fq_var = svgp_flops_per_query(Z, D, T)
+    achieved = fq_var * M / (kern_ms * 1e-3) / 1e12
+    traffic, traffic_source = pmc_traffic("svgp", Z, M)
+    return {"workload": f"BASELINE configs[4]: SVGP exact conversion, Z={Z} inducing pts, T=D=3, M={M} queries per GPU "
+                        "per step, mean+std+Jacobian+Jacobian std, fp32 prediction (fp64 factorisation)",
+            "value": world * M * steps / elapsed, "elapsed_s": elapsed, "ms_per_step": elapsed / steps * 1e3, "fit_ms": fit_ms,
+            "flops_per_query": fq,
+            "roofline": {"bound": "mfma", "kernel": "k_var<float> (stacked per-task triangular MFMA GEMM, v_mfma_f32_16x16x4_f32)",
+                         "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel_ms": kern_ms, "mean_jac_kernel_ms": mj_ms}}
+
+
 def run_svgp(args):
-    """BASELINE configs[4]: SVGP-MIMO derivative path, 2048 inducing points, T = D = 3, M = 1e6 queries, fp32.
-    A step = mean (M,T), variance (M,T), Jacobian (M,T,D) and Jacobian variance (M,T,D) of one resident batch."""
+    """`--config svgp`: BASELINE configs[4] as the headline of the JSON line (one rank, or sharded like the exact path)."""
     from gaussian_process_transportation_amd import _lib
     torch, dist, h, rank, world, dev, use_dist, ranks_seen = init_ranks(args)
     Z, T, D = args.inducing, 3, 3
@@ -406,40 +556,20 @@ def run_svgp(args):
         h.fit_svgp(Zp, y, Sigma, ls, osc, dtype=_lib.GPT_F32)
         fit_ms = (time.perf_counter() - t0) * 1e3
     bcast_ms, bcast_bytes = broadcast_fitted(torch, dist, h, rank, dev, use_dist)
-    xq = torch.from_numpy(np.random.default_rng(1 + rank).uniform(-0.1, 1.1, (M, D)).astype(np.float32)).to(dev)
-    f32 = torch.float32
-    mean = torch.empty((M, T), dtype=f32, device=dev); var = torch.empty((M, T), dtype=f32, device=dev)
-    J = torch.empty((M, T, D), dtype=f32, device=dev); Jvar = torch.empty((M, T, D), dtype=f32, device=dev)
-    h.reserve(M, True)
-
-    def step():
-        h.predict_all_dev(xq.data_ptr(), M, mean.data_ptr(), var.data_ptr(), J.data_ptr(), Jvar.data_ptr(), 0)
-
-    elapsed, kern_ms, mj_ms = timed_steps(torch, dist, h, step, args, dev, use_dist)
-    ok = bool(torch.isfinite(mean).all() and torch.isfinite(J).all() and torch.isfinite(var).all() and torch.isfinite(Jvar).all()
-              and float(var.min()) >= 0.0 and float(var.max()) <= 1.0 + 1e-5)
-    if not ok and not os.environ.get("GPT_BENCH_ABLATE"):     # timing-only ablation builds compute wrong values
-        raise SystemExit("bench (svgp): non-finite or out-of-range outputs")
+    rec = measure_svgp((torch, dist, None, rank, world, dev, use_dist), args, Z, M, args.steps, args.warmup, h=h)
     if rank == 0:
-        value = world * M * args.steps / elapsed
-        fq, fq_var = svgp_flops_per_query(Z, D, T)
-        achieved = fq_var * M / (kern_ms * 1e-3) / 1e12
-        traffic, traffic_source = pmc_traffic("svgp", Z, M)
         out = {
             "metric": "SVGP-MIMO posterior (mean+std+Jacobian+Jacobian std) preds/sec, 2048 inducing pts, 3 tasks, 3-D fp32",
-            "value": value, "unit": "predictions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "value": rec["value"], "unit": "predictions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[4]: SVGP exact conversion, Z={Z} inducing pts, T=D=3, M={M} queries per GPU "
-                                   "per step, mean+std+Jacobian+Jacobian std, fp32 prediction (fp64 factorisation)",
-                       "inducing": Z, "tasks": T, "queries_per_gpu": M},
-            "flops_per_query": fq, "achieved_tflops_whole_path": value * fq / 1e12 / world,
-            "roofline": {"bound": "mfma", "kernel": "k_var<float> (stacked per-task triangular MFMA GEMM, v_mfma_f32_16x16x4_f32)",
-                         "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel_ms": kern_ms, "mean_jac_kernel_ms": mj_ms},
+            "config": {"workload": rec["workload"], "inducing": Z, "tasks": T, "queries_per_gpu": M},
+            "flops_per_query": rec["flops_per_query"], "achieved_tflops_whole_path": rec["value"] * rec["flops_per_query"] / 1e12 / world,
+            "roofline": rec["roofline"],
             "fit_ms": fit_ms, "bcast_ms": bcast_ms, "bcast_bytes": bcast_bytes, "ranks_seen": ranks_seen,
         }
+        if use_dist and bcast_ms is not None:
+            out["value_incl_bcast"] = world * M * args.steps / (rec["elapsed_s"] + bcast_ms * 1e-3)
         out["cpu_baseline"] = svgp_cpu_baseline(Z, args.cpu_sample * 5) if world == 1 and args.cpu_sample > 0 else None
         print(json.dumps(out), flush=True)
     h.close()

@@ -757,6 +757,19 @@ static int potrf_group(int NP) {
     return grp_env ? grp_env : (NP >= 4096 ? 2 : 1);
 }
 
+// Trailing update of the Cholesky: A[row0.., row0..row0+ncols) -= P P^T on the block lower triangle, P = A[row0.., kcol0..kcol0+kw)
+static void syrk_update(hipStream_t s, double* K, int NP, int row0, int ncols, int kcol0, int kw) {
+    const int rem = NP - row0;
+    if (rem <= 0 || kw <= 0) return;
+    GemmArgs c{};
+    c.A = K + (size_t)row0 * NP + kcol0; c.lda = NP;
+    c.B = c.A; c.ldb = NP;
+    c.C = K + (size_t)row0 * NP + row0; c.ldc = NP;
+    c.M = c.M_last = rem; c.N = ncols < rem ? ncols : rem; c.K = c.K_last = kw; c.nbatch = 1;
+    c.alpha = -1.0; c.beta = 1.0; c.lower_only = 1;
+    launch_gemm<true>(s, c);
+}
+
 static void potrf_groups(hipStream_t s, double* K, double* W, int NP, int* info, int blk_begin, int blk_end) {
     const int nb = NP / NB;
     const int ob = potrf_outer_blocks();
@@ -774,17 +787,7 @@ static void potrf_groups(hipStream_t s, double* K, double* W, int NP, int* info,
     // (measured: groups of 2 take 3 % off the Cholesky at N = 8192 and add 3-5 % at N <= 2500, where the extra thin GEMM
     // on the chain costs more than the trailing matrix's traffic; tools/gpu_fit_ab.sh with GPT_POTRF_GROUP)
     const int grp = potrf_group(NP);
-    auto syrk = [&](int row0, int ncols, int kcol0, int kw) {      // A[row0.., row0..row0+ncols) -= P P^T, P = A[row0.., kcol0..kcol0+kw)
-        const int rem = NP - row0;
-        if (rem <= 0 || kw <= 0) return;
-        GemmArgs c{};
-        c.A = K + (size_t)row0 * NP + kcol0; c.lda = NP;
-        c.B = c.A; c.ldb = NP;
-        c.C = K + (size_t)row0 * NP + row0; c.ldc = NP;
-        c.M = c.M_last = rem; c.N = ncols < rem ? ncols : rem; c.K = c.K_last = kw; c.nbatch = 1;
-        c.alpha = -1.0; c.beta = 1.0; c.lower_only = 1;
-        launch_gemm<true>(s, c);
-    };
+    auto syrk = [&](int row0, int ncols, int kcol0, int kw) { syrk_update(s, K, NP, row0, ncols, kcol0, kw); };
     const int gw = grp * ob;                                        // blocks per group
     for (int g0 = blk_begin; g0 < blk_end; g0 += gw) {
         const int gend = g0 + gw < nb ? g0 + gw : nb;

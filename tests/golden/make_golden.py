@@ -225,6 +225,51 @@ def case_matern(pt, resample):
     print("wrote matern_2d", np.exp(out["opt_theta"]), out["opt_lml"])
 
 
+def case_matern5d(pt):
+    """Matern-nu on a 5-D input (the wide source layout of the HIP path, rows of 8): the reference class with
+    optimizer=None for nu = 0.5 / 1.5 / 2.5, ARD and isotropic length-scales, N = 300 (off every tile boundary):
+    alpha_, diag L, mean, std, covariance, LML value + gradient at the kernel's theta and at a perturbed one."""
+    from sklearn.gaussian_process.kernels import Matern, WhiteKernel, ConstantKernel as C
+    rng = np.random.default_rng(21)
+    N, M, D, O = 300, 90, 5, 2
+    X = rng.uniform(0, 1, (N, D))
+    Y = np.column_stack([np.sin(3 * X[:, 0]) * X[:, 3], np.cos(2 * X[:, 1] + X[:, 4])]) + 0.02 * rng.standard_normal((N, O))
+    Xq = rng.uniform(-0.1, 1.1, (M, D))
+    ls = np.array([0.6, 0.9, 0.7, 1.1, 0.8])
+    out = dict(X=X, Y=Y, Xq=Xq, alpha=np.float64(1e-10), constant_value=np.float64(0.3), length_scale=ls,
+               noise_level=np.float64(0.01), iso_length_scale=np.float64(0.8))
+    rs = np.random.default_rng(6)
+    for nu, tag in ((0.5, "12"), (1.5, "32"), (2.5, "52")):
+        for kind, lsk in (("ard", ls), ("iso", 0.8)):
+            gp = pt.GaussianProcess(kernel=C(0.3) * Matern(lsk, nu=nu) + WhiteKernel(0.01), optimizer=None)
+            gp.fit(X, Y)
+            m, s = gp.predict(Xq, return_std=True)
+            _, cov = gp.predict(Xq[:12], return_cov=True)
+            ths, vals, grads = [], [], []
+            base = gp.gp.kernel_.theta.copy()
+            for j in range(2):
+                th = base + j * rs.normal(0, 0.3, base.shape)
+                v, gr = gp.gp.log_marginal_likelihood(th, eval_gradient=True)
+                ths.append(th); vals.append(v); grads.append(gr)
+            pre = f"m{tag}_{kind}_"
+            out.update({pre + "mean": m, pre + "std": s, pre + "cov": cov, pre + "alpha_": gp.gp.alpha_,
+                        pre + "Ldiag": np.diag(gp.gp.L_).copy(), pre + "lml_theta": np.array(ths),
+                        pre + "lml_value": np.array(vals), pre + "lml_grad": np.array(grads)})
+    np.savez_compressed(os.path.join(HERE, "matern_5d.npz"), **out)
+    print("wrote matern_5d", {k: np.shape(v) for k, v in out.items() if k.startswith("m52_ard")})
+
+
+def case_robot_demo():
+    """The recorded robot demonstration the reference ships (data/last.npz, loaded with allow_pickle=False: plain float
+    arrays): positions (102,3), orientations as quaternions (102,4) and velocities (102,3) — the inputs of
+    transport_orientation (policy_transportation.py:61-77) in the reference's own robot use.  Data only; the source /
+    target distributions of that experiment are pickles (distributions/*.pkl) and are NOT loaded."""
+    z = np.load(os.path.join(REF, "data/last.npz"), allow_pickle=False)
+    out = {k: z[k] for k in ("training_traj", "training_ori", "training_delta")}
+    np.savez_compressed(os.path.join(HERE, "robot_demo_last.npz"), **out)
+    print("wrote robot_demo_last", {k: v.shape for k, v in out.items()})
+
+
 def case_surface3d(pt, optimize=True):
     """example/3D/surface_generalization_3D.py:50-61 flow (N=2500, default kernel).
     optimizer on takes ~5 min here; the fitted theta is stored and outputs come from
@@ -276,7 +321,7 @@ def case_n8192(pt):
 def main(argv):
     warnings.filterwarnings("ignore")
     pt, resample = import_reference()
-    cases = argv or ["n64", "n64iso", "n64nan", "n256", "n1024", "n200d5", "n128d8", "letterS", "matern"]
+    cases = argv or ["n64", "n64iso", "n64nan", "n256", "n1024", "n200d5", "n128d8", "letterS", "matern", "matern5d", "robot"]
     for c in cases:
         if c == "n64":
             case_synthetic(pt, 64, 48, "synthetic_3d_N64", with_cov=16)
@@ -296,6 +341,10 @@ def main(argv):
             case_letterS(pt, resample)
         elif c == "matern":
             case_matern(pt, resample)
+        elif c == "matern5d":
+            case_matern5d(pt)
+        elif c == "robot":
+            case_robot_demo()
         elif c == "surface3d":
             case_surface3d(pt, optimize=True)
         elif c == "n8192":

@@ -1180,3 +1180,211 @@ def test_concurrent_restart_runs_are_bit_identical_to_sequential_ones(monkeypatc
             assert np.array_equal(out[workers][0], out["1"][0]) and out[workers][1] == out["1"][1]
             assert out[workers][2] == out["1"][2]                      # the RNG stream continues from the same state
     assert_parity(out["1"][0], out["6"][0], 0.0, "theta")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The launch shapes bench.py times, checked against reference vectors (not only against identities): the golden
+# queries are scattered through batches of the benchmark's size, so they pass through the whole-round path of k_var
+# (rounds of 256 column blocks, nbi = 16 i-blocks per block at N = 8192) in many rounds and workgroups.
+# ---------------------------------------------------------------------------------------------------------------
+def _predict_dev(h, Xq, mean=False, var=False, J=False, Jvar=False, dvar=False):
+    """One gpt_predict_all_dev launch on device-resident queries — the call bench.py times — results as numpy."""
+    import torch
+    N, D, O, _ = h.info()
+    nt, dt = h.model_info()
+    from gaussian_process_transportation_amd import _lib
+    ty = torch.float64 if dt == _lib.GPT_F64 else torch.float32
+    dev = torch.device("cuda", 0)
+    xq = torch.from_numpy(np.ascontiguousarray(Xq)).to(dev, dtype=ty)
+    M = xq.shape[0]
+    vshape, jvshape = ((M,), (M, D)) if nt == 1 else ((M, nt), (M, nt, D))
+    bufs = {"mean": torch.empty((M, O), dtype=ty, device=dev) if mean else None,
+            "var": torch.empty(vshape, dtype=ty, device=dev) if var else None,
+            "J": torch.empty((M, O, D), dtype=ty, device=dev) if J else None,
+            "Jvar": torch.empty(jvshape, dtype=ty, device=dev) if Jvar else None,
+            "dvar": torch.empty((D, M), dtype=ty, device=dev) if dvar else None}
+    torch.cuda.synchronize()
+    h.predict_all_dev(xq.data_ptr(), M, *[(bufs[k].data_ptr() if bufs[k] is not None else 0) for k in ("mean", "var", "J", "Jvar", "dvar")])
+    h.synchronize()
+    return {k: (v.cpu().numpy() if v is not None else None) for k, v in bufs.items()}
+
+
+def _golden_n8192_model():
+    from gaussian_process_transportation_amd import _lib
+    g = load_golden("synthetic_3d_N8192")
+    rng = np.random.default_rng(0)
+    X = rng.uniform(0, 1, (8192, 3))
+    Y = 0.05 * np.sin(4 * X) + 0.01 * rng.standard_normal((8192, 3))
+    h = _lib.Handle(0)
+    h.fit(X, Y, g["length_scale"], float(g["constant_value"]), float(g["noise_level"]), float(g["alpha"]))
+    return g, h
+
+
+def _check_golden_rows(g, out1, out4, rows, what):
+    noise = float(g["noise_level"])
+    std1 = np.sqrt(out1["var"][rows]) - np.sqrt(noise)           # gaussian_process.py:49
+    std4 = np.sqrt(out4["var"][rows]) - np.sqrt(noise)
+    assert_parity(out1["mean"][rows], g["mean"], RTOL, f"mean ({what})")
+    assert_parity(std1, g["std"][:, 0], RTOL, f"std, 1-column launch ({what})")
+    assert_parity(out1["J"][rows], g["J"], RTOL, f"J ({what})")
+    assert_parity(std4, g["std"][:, 0], RTOL, f"std, fused launch ({what})")
+    assert_parity(out4["Jvar"][rows], g["Jvar"][:, 0, :], RTOL, f"Jvar ({what})")
+    assert_parity(out4["dvar"][:, rows], g["dvar"], RTOL, f"dvar ({what})")
+
+
+def test_headline_launch_shape_against_reference_vectors():
+    """BASELINE configs[2] exactly as bench.py launches it — N = 8192, ONE device-pointer call over M = 500 000 resident
+    queries, mode J (mean + var + Jacobian, 1 column per query: 7813 column blocks = 30 whole rounds + a tail) and the
+    fused 4-column launch (31 250 blocks = 122 rounds + a tail) — with the reference's own 256 golden queries
+    (tests/golden/synthetic_3d_N8192.npz, captured from gaussian_process.py:46-55, 63-126 run in the authoring
+    container) scattered through the batch at stride 1953, i.e. through different rounds and workgroups."""
+    g, h = _golden_n8192_model()
+    M, stride = 500_000, 1953
+    Xq = np.random.default_rng(1).uniform(-0.1, 1.1, (M, 3))
+    rows = np.arange(256) * stride
+    assert rows[-1] < M
+    Xq[rows] = g["Xq"]
+    out1 = _predict_dev(h, Xq, mean=True, var=True, J=True)                 # bench.py's step
+    out4 = _predict_dev(h, Xq, var=True, Jvar=True, dvar=True)              # bench.py --jvar's variance launch (+ dvar)
+    _check_golden_rows(g, out1, out4, rows, "M=500k, whole rounds")
+    # the golden rows sit in 256 different column blocks of the 1-column launch, in rounds 0 .. 30, and the two launches
+    # agree on every row (two instantiations, two work splits)
+    assert len(set((rows // 64).tolist())) == 256 and (rows[-1] // 64) // 256 >= 29
+    assert_parity(out4["var"], out1["var"], 1e-10, "var: fused vs 1-column launch, all 500k rows")
+    assert out1["var"].min() >= 0.0 and out1["var"].max() <= float(g["constant_value"]) + float(g["noise_level"]) + 1e-12
+    h.close()
+
+
+def test_reference_grid_size_at_n8192_against_reference_vectors():
+    """N = 8192 with M = 10^4 queries — the size of the reference's plotting grids (plot_utils.py:13, 287-288): 157
+    column blocks on 256 workgroups, i.e. the item-list / cut-sweep path with many blocks, against the golden queries
+    scattered at stride 39."""
+    g, h = _golden_n8192_model()
+    M, stride = 10_000, 39
+    Xq = np.random.default_rng(2).uniform(-0.1, 1.1, (M, 3))
+    rows = np.arange(256) * stride
+    Xq[rows] = g["Xq"]
+    out1 = _predict_dev(h, Xq, mean=True, var=True, J=True)
+    out4 = _predict_dev(h, Xq, var=True, Jvar=True, dvar=True)
+    _check_golden_rows(g, out1, out4, rows, "M=10^4, cut sweeps")
+    assert_parity(out4["var"], out1["var"], 1e-10, "var: fused vs 1-column launch")
+    # and the host-buffer entry point on the same batch
+    host = h.predict_all(Xq, mean=True, var=True, J=True)
+    assert np.array_equal(host["mean"], out1["mean"]) and np.array_equal(host["J"], out1["J"]) and np.array_equal(host["var"], out1["var"])
+    h.close()
+
+
+def test_svgp_fp32_bench_launch_shape_against_oracle():
+    """BASELINE configs[4] as `bench.py --config svgp` launches it: Z = 2048 inducing points, T = D = 3, fp32, ONE
+    device-pointer call over M = 10^6 resident queries (the stacked-task whole-round path: 62 500 column blocks, nbi = 4),
+    1024 strided rows against the fp64 CPU restatement.  PARITY UNPINNED (gpytorch absent, the reference holds no
+    fixture); tolerance as test_svgp_fp32_config5_shape: no worse than the same algebra in numpy float32, and 1e-4 of
+    the array scale."""
+    from gaussian_process_transportation_amd import _lib
+    from oracle import gp_oracle as orc
+    M = 1_000_000
+    Z, Sigma, y, osc, ls, Xq = orc.svgp_synthetic_problem(2048, M)
+    rows = np.arange(1024) * 976 + 7
+    assert rows[-1] < M
+    ref64 = orc.svgp_exact_oracle_fast(Xq[rows], Z, Sigma, y, osc, ls)
+    ref32 = orc.svgp_exact_oracle_fast(Xq[rows], Z, Sigma, y, osc, ls, dtype=np.float32)
+    h = _lib.Handle(0)
+    h.fit_svgp(Z, y, Sigma, ls, osc, dtype=_lib.GPT_F32)
+    out = _predict_dev(h, Xq, mean=True, var=True, J=True, Jvar=True)       # bench.py's svgp step
+    assert out["var"].dtype == np.float32 and out["var"].shape == (M, 3) and out["Jvar"].shape == (M, 3, 3)
+    got = (out["mean"][rows], np.sqrt(np.maximum(out["var"][rows], 0)), out["J"][rows], np.sqrt(np.maximum(out["Jvar"][rows], 0)))
+    for name, g32, r64, r32 in zip(("mean", "std", "J", "J std"), got, ref64, ref32):
+        scale = np.max(np.abs(r64))
+        err_gpu = np.max(np.abs(g32.astype(np.float64) - r64)) / scale
+        err_ref_arith = np.max(np.abs(r32.astype(np.float64) - r64)) / scale
+        print(f"svgp fp32 M=1e6 {name}: GPU {err_gpu:.2e}, reference arithmetic {err_ref_arith:.2e} (relative to {scale:.3g})")
+        assert err_gpu <= err_ref_arith and err_gpu <= 1e-4, (name, err_gpu, err_ref_arith)
+    assert np.all(np.isfinite(out["mean"])) and np.all(np.isfinite(out["J"]))
+    assert out["var"].min() >= 0.0 and out["var"].max() <= 1.0 + 1e-5
+    h.close()
+
+
+@pytest.mark.parametrize("tag,nu,code", [("12", 0.5, 1), ("32", 1.5, 2), ("52", 2.5, 3)])
+def test_matern_kernels_in_five_dimensions_vs_reference(tag, nu, code):
+    """Matern x the wide layout (D = 5: k_gram<MAX_D>, k_mean_jac<.., KT_MATERN*, MAX_D>, k_var wide with a Matern KT,
+    k_lml_terms wide): fit, mean, std, covariance, LML + gradient against the reference class (matern_5d.npz, ARD and
+    isotropic), and the same model in fp32 against the fp64 result."""
+    from sklearn.gaussian_process.kernels import Matern, WhiteKernel, ConstantKernel as C
+    from gaussian_process_transportation_amd import GaussianProcess, _lib
+    g = load_golden("matern_5d")
+    for kk, ls, n_ls in (("ard", g["length_scale"], 5), ("iso", float(g["iso_length_scale"]), 1)):
+        pre = f"m{tag}_{kk}_"
+        gp = GaussianProcess(kernel=C(0.3) * Matern(ls, nu=nu) + WhiteKernel(0.01), optimizer=None, verbose=False)
+        gp.fit(g["X"], g["Y"])
+        assert_parity(gp.gp.alpha_, g[pre + "alpha_"], RTOL, "alpha_")
+        assert_parity(np.diag(gp.gp.L_), g[pre + "Ldiag"], RTOL, "diag L")
+        m, s = gp.predict(g["Xq"], return_std=True)
+        assert_parity(m, g[pre + "mean"], RTOL, "mean")
+        assert_parity(s, g[pre + "std"], RTOL, "std")
+        _, cov = gp.predict(g["Xq"][:12], return_cov=True)
+        assert_parity(cov, g[pre + "cov"], RTOL, "cov")
+        h = _lib.Handle(0)
+        for th, v, gr in zip(g[pre + "lml_theta"], g[pre + "lml_value"], g[pre + "lml_grad"]):
+            h.fit(g["X"], g["Y"], np.exp(th[1:1 + n_ls]), np.exp(th[0]), np.exp(th[1 + n_ls]), 1e-10, code)
+            lml, grad = h.lml_gradient(n_ls)
+            assert lml == pytest.approx(float(v), rel=1e-9)
+            assert_parity(grad, gr, 1e-6, f"d lml / d theta ({kk})")
+        # Matern x fp32: fp64 factorisation, fp32 prediction kernels; against the fp64 model at fp32's resolution
+        big = np.random.default_rng(3).uniform(-0.1, 1.1, (3000, 5))
+        lsv = np.atleast_1d(np.asarray(ls, dtype=float))
+        h.fit(g["X"], g["Y"], lsv, 0.3, 0.01, 1e-10, code)
+        o64 = h.predict_all(big, mean=True, var=True)
+        h.set_dtype(_lib.GPT_F32)
+        h.fit(g["X"], g["Y"], lsv, 0.3, 0.01, 1e-10, code)
+        o32 = h.predict_all(big, mean=True, var=True)
+        assert o32["mean"].dtype == np.float32
+        assert_parity(o32["mean"], o64["mean"], 2e-4, "mean (Matern, fp32 model)")
+        assert np.max(np.abs(o32["var"] - o64["var"])) < 2e-4 * 0.31
+        with pytest.raises(ValueError):
+            h.predict_all(big[:5], J=True)                     # RBF-only formulas (reference quirk 6): refused
+        h.close()
+
+
+def test_transport_orientation_on_the_recorded_robot_demo():
+    """transport_orientation (policy_transportation.py:61-77) fed with the reference's own recorded demonstration
+    (data/last.npz: 102 positions, quaternions and velocities of the robot, stored as arrays in robot_demo_last.npz).
+    PARITY UNPINNED — the reference's `Quaternion` module is absent and its repo holds no transported orientation — so
+    this stays a property test: unit norm, R(out) = polar(J_Phi) R(in) with J_Phi at the UN-rotated positions (the
+    reference's quirk), and the identity map leaves the orientations unchanged.  The source / target surfaces of the
+    recorded experiment are pickles and are not loaded: a synthetic surface pair under the trajectory stands in."""
+    from gaussian_process_transportation_amd import GaussianProcessTransportation
+    from gaussian_process_transportation_amd.quaternion import rotation_matrix_from_quaternion
+    g = load_golden("robot_demo_last")
+    traj, ori, vel = g["training_traj"], g["training_ori"], g["training_delta"]
+    assert traj.shape == (102, 3) and ori.shape == (102, 4)
+    assert_parity(np.linalg.norm(ori, axis=1), np.ones(102), 1e-5, "recorded quaternions are unit (to 2.5e-6)")
+    lo, hi = traj.min(0) - 0.05, traj.max(0) + 0.05
+    gx, gy = np.meshgrid(np.linspace(lo[0], hi[0], 20), np.linspace(lo[1], hi[1], 20))
+    src = np.column_stack([gx.ravel(), gy.ravel(), np.full(gx.size, lo[2])])
+    ang = 0.3
+    Rz = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1.0]])
+    span = hi - lo
+    tgt = (src - src.mean(0)) @ Rz.T + src.mean(0) + np.array([0.02, -0.01, 0.03])
+    tgt[:, 2] += 0.15 * span[0] * np.sin(2 * np.pi * (src[:, 0] - lo[0]) / span[0]) * np.cos(np.pi * (src[:, 1] - lo[1]) / span[1])
+    kern = sk_kernel(0.05, [0.6 * float(np.max(span[:2]))], 1e-5)
+    for target, identity in ((tgt, False), (src.copy(), True)):
+        tr = GaussianProcessTransportation(kernel_transport=kern, optimizer=None, verbose=False)
+        tr.source_distribution = src; tr.target_distribution = target
+        tr.training_traj = traj; tr.training_delta = vel; tr.training_ori = ori
+        tr.fit_transportation()
+        tr.apply_transportation()
+        out = tr.training_ori
+        assert out.shape == ori.shape
+        # the product with a unit quaternion keeps the norm of the recorded one (no renormalisation, as in the reference)
+        assert_parity(np.linalg.norm(out, axis=1), np.linalg.norm(ori, axis=1), 1e-9, "quaternion norm preserved")
+        J = tr.method.delta_map.derivative(traj)
+        Jg = tr.method.affine_transform.derivative(traj)
+        Jphi = Jg + J @ Jg
+        U, _, Vt = np.linalg.svd(Jphi)
+        polar = U @ Vt
+        assert np.all(np.linalg.det(Jphi) > 0)
+        Rout, Rin = rotation_matrix_from_quaternion(out), rotation_matrix_from_quaternion(ori)
+        assert np.max(np.abs(Rout - polar @ Rin)) < 5e-3
+        if identity:
+            assert np.max(np.abs(Rout - Rin)) < 1e-6
+            assert_parity(tr.training_traj, traj, 1e-6, "identity transport leaves the positions")

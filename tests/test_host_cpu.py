@@ -210,6 +210,49 @@ def test_bench_launcher_starts_its_own_ranks():
     assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["steps"] == 2
 
 
+def test_bench_launcher_starts_eight_ranks():
+    """configs[3]'s command shape, `python bench.py --gpus 8`: eight ranks rendezvous (gloo / CPU rehearsal), every rank
+    sees eight, one JSON line comes back."""
+    import json
+    r = _run_bench("--gpus", "8", "--steps", "2", "--warmup", "0", "--dry-run")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["ranks_seen"] == 8
+
+
+def test_bench_launcher_keeps_a_device_restriction_and_refuses_too_few_devices():
+    """HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES already in the environment stay in force (rank r = device r of the
+    visible set); fewer visible devices than --gpus is refused by the launcher before a single rank is started."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    r = _run_bench("--gpus", "4", "--steps", "1", "--dry-run", env_extra={"HIP_VISIBLE_DEVICES": "2,3", "GPT_BENCH_DRY_CHECK_DEVICES": "1"})
+    assert r.returncode != 0 and "HIP_VISIBLE_DEVICES" in r.stderr and "2 device(s) visible" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    r = _run_bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--dry-run", env_extra={"ROCR_VISIBLE_DEVICES": "5,6", "HIP_VISIBLE_DEVICES": "0,1", "GPT_BENCH_DRY_CHECK_DEVICES": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    old = {k: os.environ.pop(k, None) for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")}
+    try:
+        assert bench.visible_device_shortfall(8) is None
+        os.environ["HIP_VISIBLE_DEVICES"] = "0,1,2,3,4,5,6,7"
+        assert bench.visible_device_shortfall(8) is None and bench.visible_device_shortfall(9) is not None
+        os.environ["HIP_VISIBLE_DEVICES"] = "0,1,-1,3"
+        assert bench.visible_device_shortfall(2) is None and bench.visible_device_shortfall(3) is not None
+        os.environ["HIP_VISIBLE_DEVICES"] = ""
+        assert bench.visible_device_shortfall(1) is not None
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+    # the ranks themselves check the device count before the process group exists
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    init = src[src.index("def init_ranks"):src.index("def broadcast_fitted")]
+    assert init.index("torch.cuda.device_count()") < init.index("init_process_group")
+
+
 def test_bench_launcher_reports_a_failed_rank():
     """A rank that dies must not leave the launcher (or the other rank) hanging, and the exit code is not 0."""
     r = _run_bench("--gpus", "2", "--steps", "1", "--dry-run", env_extra={"GPT_BENCH_DRY_FAIL_RANK": "1"})

@@ -135,3 +135,23 @@ def test_matern_kernels(tag, kind):
     val, grad = orc.log_marginal_likelihood(g[f"m{tag}_iso_theta"], g["X"][::4], g["Y"][::4], 1, kind=kind)
     assert val == pytest.approx(float(g[f"m{tag}_iso_value"]), rel=1e-10)
     assert_parity(grad, g[f"m{tag}_iso_grad"], 1e-7, "lml grad (isotropic)")
+
+
+@pytest.mark.parametrize("tag,kind", [("12", "matern12"), ("32", "matern32"), ("52", "matern52")])
+def test_matern_kernels_in_five_dimensions(tag, kind):
+    """C * Matern(nu) + White on a 5-D input, ARD and isotropic, against the reference class (matern_5d.npz)."""
+    g = load_golden("matern_5d")
+    for kk, ls, n_ls in (("ard", g["length_scale"], 5), ("iso", np.array([float(g["iso_length_scale"])]), 1)):
+        pre = f"m{tag}_{kk}_"
+        gp = orc.GaussianProcessOracle(0.3, ls, 0.01, kind=kind).fit(g["X"], g["Y"])
+        assert_parity(gp.alpha_, g[pre + "alpha_"], 1e-7, "alpha_")
+        assert_parity(np.diag(gp.L_), g[pre + "Ldiag"], TIGHT, "diag L")
+        m, s = gp.predict(g["Xq"], return_std=True)
+        assert_parity(m, g[pre + "mean"], 1e-8, "mean")
+        assert_parity(s, g[pre + "std"], 1e-7, "std")
+        _, cov = gp.predict(g["Xq"][:12], return_cov=True)
+        assert_parity(cov, g[pre + "cov"], 1e-7, "cov")
+        for th, v, gr in zip(g[pre + "lml_theta"], g[pre + "lml_value"], g[pre + "lml_grad"]):
+            val, grad = orc.log_marginal_likelihood(th, g["X"], g["Y"], n_ls, kind=kind)
+            assert val == pytest.approx(float(v), rel=1e-10)
+            assert_parity(grad, gr, 1e-7, f"lml grad ({kk})")
