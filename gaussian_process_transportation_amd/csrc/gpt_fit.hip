@@ -526,9 +526,21 @@ struct GemmArgs {
     int a_lower;             // A lower triangular: k < i0 + TS
     int b_lower;             // B lower triangular (BT=false): k >= j0
     int k_from_ij;           // both operands vanish for k < max(i0, j0) (W^T W with W lower triangular)
+    int stagger;             // diagnostic: < 0 = rows of a folded triangle dealt round-robin over the XCDs (the round-2 order)
 };
 
 constexpr int GA_S = 34;     // [row][k] stride
+
+// One MFMA operand from LDS as a plain ds_read_b64 that hipcc cannot fuse with its neighbour.  Left alone it merges the two
+// reads of a k-step into ds_read2_b64 / ds_read2st64_b64, which the LDS serves in 16-lane groups over 32 banks: 8 cycles
+// instead of 2 x 2, and 2-way conflicts on images laid out for the 64-bank ds_read_b64 (measured on the rank-256 trailing
+// update: SQ_LDS_BANK_CONFLICT 31.6 M of 79 M LDS cycles, the LDS as busy as the matrix pipe; profiles/r03_fit_gemm_pmc.txt).
+typedef __attribute__((address_space(3))) const double* lds_cptr;
+__device__ __forceinline__ double lds_ld(const double* p) {
+    unsigned off = (unsigned)(size_t)(lds_cptr)p;
+    asm("" : "+v"(off));
+    return *(lds_cptr)(size_t)off;
+}
 
 // Tile -> workgroup mapping.  Workgroups are dealt round-robin over the 8 XCDs (linear id mod 8) and each XCD has
 // its own L2, so the 1-D grid is decoded as (xcd = id % 8, s = id / 8).  Tile rows of all batch entries are
@@ -537,6 +549,81 @@ constexpr int GA_S = 34;     // [row][k] stride
 // starts the longest tiles first (greedy longest-processing-time: the K range of a tile shrinks with tj when B is
 // triangular, grows with ti when A is, shrinks with ti for W^T W), and the ~64 workgroups it runs at a time share
 // a few row and column panels in that XCD's L2.
+#ifndef GPT_GEMM_ABL       // timing-only ablation builds of k_gemm (tools/probes/syrk_seq_probe.hip): 1 no operand loads, 2 no LDS stores,
+#define GPT_GEMM_ABL 0     // 3 no C traffic, 4 no C store, 5 no MFMAs.  Results are wrong unless 0.
+#endif
+#ifdef GPT_GEMM_TRACE      // tools/probes/gemm_tile_trace.hip: shader-clock stamps of the phases of one tile (diagnostic builds only)
+__device__ long long* g_gemm_trace = nullptr;
+#define GPT_GT(i) do { if (g_gemm_trace && threadIdx.x == 0 && blockIdx.x < 16) { long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_gemm_trace[blockIdx.x * 64 + (i)] = t_; } } while (0)
+#else
+#define GPT_GT(i) do { } while (0)
+#endif
+// ---- tile -> workgroup decode shared by the tile bodies (see the comment above gemm_tile) -------------------------
+struct TilePos { int b, ti, tj; bool ok; };
+__device__ __forceinline__ TilePos gemm_decode(const GemmArgs& g, int TM, int TN, int G, int fold_tm, const int vid) {
+    TilePos t{0, 0, 0, false};
+    const int xcd = vid & 7, sidx = vid >> 3;
+    if (fold_tm < 0) {
+        // Square lower-triangular tile set (T x T, tj <= ti) in BANDS of 8 consecutive tile rows: band beta goes whole to one
+        // XCD (bands dealt boustrophedon, 0..7, 7..0, ..., so every XCD gets long and short ones; longest first), and the XCD
+        // walks a band column by column, its 8 rows together.  The ~128 tiles an XCD runs at a time are then 8 rows x 16
+        // columns of ONE band: 8 row panels that stay in its L2 for the whole band and a sliding window of 16 column panels,
+        // each read once per band — where the folded order above has every row of the XCD stream its own diagonal of column
+        // panels (36 % of the panel requests of a rank-256 update missed L2: profiles/r03_fit_gemm_pmc.txt).
+        const int T = -fold_tm;
+        const int nbands = (T + 7) / 8;
+        int rem = sidx, r0 = 0, nr = 0;
+        bool found = false;
+        for (int k = (nbands - 1) / 8; k >= 0; --k) {
+            const int beta = 8 * k + ((k & 1) ? 7 - xcd : xcd);
+            if (beta >= nbands) continue;
+            r0 = 8 * beta;
+            nr = T - r0 < 8 ? T - r0 : 8;
+            const int cnt = r0 * nr + nr * (nr + 1) / 2;
+            if (rem < cnt) { found = true; break; }
+            rem -= cnt;
+        }
+        if (!found) return t;
+        if (rem < r0 * nr) { t.tj = rem / nr; t.ti = r0 + rem % nr; }
+        else {
+            rem -= r0 * nr;
+            int c = 0;
+            while (rem >= nr - c) { rem -= nr - c; ++c; }
+            t.tj = r0 + c; t.ti = r0 + c + rem;
+        }
+        t.ok = true;
+        return t;
+    }
+    int gi;
+    if (g.a_lower)        { gi = G - 1 - sidx / TN; t.tj = sidx % TN; }     // long rows first
+    else if (g.k_from_ij) { gi = sidx / TN;         t.tj = sidx % TN; }     // short offsets first
+    else                  { t.tj = sidx / G;        gi = sidx % G; }        // column by column
+    int R = 8 * gi + ((gi & 1) ? 7 - xcd : xcd);
+    if (fold_tm && g.stagger >= 0 && !g.k_from_ij) {
+        // folded triangle: every row of the fold has the same number of tiles, so an XCD can take CONTIGUOUS rows
+        // [xcd TM / 8, (xcd + 1) TM / 8) and stay balanced.  Its G rows then share their column panels: in the first part of
+        // the walk (tj <= ti) all rows read column panel tj, in the second part (tile (T-1-u, tj-u-1)) a window of G
+        // consecutive panels that slides by one per step — where rows dealt round-robin over the XCDs each stream a
+        // diagonal of their own (36 % of the panel requests of a rank-256 update missed L2: profiles/r03_fit_gemm_pmc.txt).
+        const int lo = xcd * TM / 8, hi = (xcd + 1) * TM / 8;
+        R = lo + gi;
+        if (R >= hi) return t;
+    }
+    t.b = R / TM;
+    t.ti = R - t.b * TM;
+    if (t.b >= g.nbatch) return t;
+    if (fold_tm) {
+        const int u = t.ti, v = t.tj;
+        if (v <= u) { t.ti = u; t.tj = v; }
+        else {
+            t.ti = fold_tm - 1 - u; t.tj = v - u - 1;
+            if (t.ti == u) return t;
+        }
+    }
+    t.ok = true;
+    return t;
+}
+
 template <bool BT, bool AT, int TS>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int TM, int TN, int G, int fold_tm, const int vid, double* smem) {
     constexpr int WS = TS / 2;              // wave tile edge
@@ -545,29 +632,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int TM, int TN, int
     constexpr int NP_ = TS / 16;            // staging passes per operand and chunk (one 16-byte load per thread each)
     double* As = smem;                                       // [TS][GA_S]   (AT: [32][GB_S])
     double* Bs = smem + (AT ? 32 * GB_S : TS * GA_S);        // BT: [TS][GA_S]   else: [32][GB_S]
-    int b, ti, tj;
-    {
-        const int xcd = vid & 7, sidx = vid >> 3;
-        int gi;
-        if (g.a_lower)        { gi = G - 1 - sidx / TN; tj = sidx % TN; }     // long rows first
-        else if (g.k_from_ij) { gi = sidx / TN;         tj = sidx % TN; }     // short offsets first
-        else                  { tj = sidx / G;          gi = sidx % G; }      // column by column
-        const int R = 8 * gi + ((gi & 1) ? 7 - xcd : xcd);
-        b = R / TM;
-        ti = R - b * TM;
-        if (b >= g.nbatch) return;
-        if (fold_tm) {
-            // square lower-triangular tile set (fold_tm x fold_tm, tj <= ti) folded into a (fold_tm+1)/2 x (fold_tm+1)
-            // rectangle: row u carries tile row u (u+1 tiles) and tile row fold_tm-1-u (fold_tm-u tiles) — no empty
-            // workgroups and the same number of tiles in every row
-            const int u = ti, v = tj;
-            if (v <= u) { ti = u; tj = v; }
-            else {
-                ti = fold_tm - 1 - u; tj = v - u - 1;
-                if (ti == u) return;                        // odd fold_tm: the middle row is covered by the first half
-            }
-        }
-    }
+    const TilePos tp = gemm_decode(g, TM, TN, G, fold_tm, vid);
+    if (!tp.ok) return;
+    const int b = tp.b, ti = tp.ti, tj = tp.tj;
     const bool last = (b == g.nbatch - 1);
     const int M = last ? g.M_last : g.M;
     const int K = last ? g.K_last : g.K;
@@ -591,7 +658,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int TM, int TN, int
     d4 acc[RT][RT];
     const double cscale = g.beta != 0.0 ? g.beta / g.alpha : 0.0;
     double* const ctile = C + (size_t)(i0 + WS * wr + lk) * g.ldc + j0 + WS * wc + lc;     // this lane's first element
-    if (active && cscale != 0.0) {          // one uniform branch, then all the loads in flight together
+    if (active && cscale != 0.0 && GPT_GEMM_ABL != 3) {          // one uniform branch, then all the loads in flight together
 #pragma unroll
         for (int r = 0; r < RT; ++r)
 #pragma unroll
@@ -622,6 +689,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int TM, int TN, int
     const bool okA_n = (i0 + kn_n) < M, okB_n = (j0 + kn_n) < N;     // all dims are multiples of 64
     d2 pa[NP_], pb[NP_];
     auto fetch = [&](int kc) {
+        if (GPT_GEMM_ABL == 1) return;               // timing-only ablation: no operand loads
 #pragma unroll
         for (int u = 0; u < NP_; ++u) {
             if (!AT) {
@@ -641,6 +709,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int TM, int TN, int
         }
     };
     auto stage = [&]() {
+        if (GPT_GEMM_ABL == 2) { asm volatile("" :: "v"(pa[0]), "v"(pb[0]), "v"(pa[NP_ - 1]), "v"(pb[NP_ - 1])); return; }   // no LDS stores
 #pragma unroll
         for (int u = 0; u < NP_; ++u) {
             if (!AT) *reinterpret_cast<d2*>(&As[(rk_r + 16 * u) * GA_S + rk_k]) = pa[u];
@@ -649,33 +718,48 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int TM, int TN, int
             else     *reinterpret_cast<d2*>(&Bs[(kn_k + KN_R * u) * GB_S + kn_n]) = pb[u];
         }
     };
+    GPT_GT(0);
     if (kbeg < kend) fetch(kbeg);
+    GPT_GT(1);
     for (int kc = kbeg; kc < kend; kc += 32) {
         stage();
+        GPT_GT(2 + 3 * ((kc - kbeg) / 32));
         __syncthreads();
         if (kc + 32 < kend) fetch(kc + 32);
+        GPT_GT(3 + 3 * ((kc - kbeg) / 32));
         if (active) {
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
                 double a[RT], bb[RT];
 #pragma unroll
                 for (int r = 0; r < RT; ++r)
-                    a[r] = AT ? As[(4 * s + lk) * GB_S + WS * wr + 16 * r + lc]
-                              : As[(WS * wr + 16 * r + lc) * GA_S + 4 * s + lk];
+                    a[r] = lds_ld(AT ? &As[(4 * s + lk) * GB_S + WS * wr + 16 * r + lc]
+                                     : &As[(WS * wr + 16 * r + lc) * GA_S + 4 * s + lk]);
 #pragma unroll
                 for (int c = 0; c < RT; ++c)
-                    bb[c] = BT ? Bs[(WS * wc + 16 * c + lc) * GA_S + 4 * s + lk]
-                               : Bs[(4 * s + lk) * GB_S + WS * wc + 16 * c + lc];
+                    bb[c] = lds_ld(BT ? &Bs[(WS * wc + 16 * c + lc) * GA_S + 4 * s + lk]
+                                      : &Bs[(4 * s + lk) * GB_S + WS * wc + 16 * c + lc]);
 #pragma unroll
                 for (int r = 0; r < RT; ++r)
 #pragma unroll
-                    for (int c = 0; c < RT; ++c)
+                    for (int c = 0; c < RT; ++c) {
+                        if (GPT_GEMM_ABL == 5) { asm volatile("" :: "v"(a[r]), "v"(bb[c])); continue; }      // no MFMAs
                         acc[r][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r], bb[c], acc[r][c], 0, 0, 0);
+                    }
             }
         }
+        GPT_GT(4 + 3 * ((kc - kbeg) / 32));
         __syncthreads();
     }
+    GPT_GT(60);
     if (!active) return;
+    if (GPT_GEMM_ABL == 3 || GPT_GEMM_ABL == 4) {          // no C traffic at all (3) / no store (4): keep the accumulators alive
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int c = 0; c < RT; ++c) asm volatile("" :: "v"(acc[r][c]));
+        return;
+    }
     const double alpha = g.alpha;
 #pragma unroll
     for (int r = 0; r < RT; ++r)
@@ -683,6 +767,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int TM, int TN, int
         for (int c = 0; c < RT; ++c)
 #pragma unroll
             for (int e = 0; e < 4; ++e) ctile[(size_t)(16 * r + 4 * e) * g.ldc + 16 * c] = alpha * acc[r][c][e];
+    GPT_GT(61);
 }
 
 template <bool BT, bool AT, int TS>
@@ -700,16 +785,56 @@ static GemmGrid gemm_grid(const GemmArgs& g, int TS) {
     // operand prefetch, tried first on the theory that the tile's K loop was latency-bound, changed nothing.)
     const int Mmax = g.nbatch == 1 ? g.M_last : (g.M > g.M_last ? g.M : g.M_last);
     q.TM = (Mmax + TS - 1) / TS; q.TN = (g.N + TS - 1) / TS;
-    if (g.lower_only && g.nbatch == 1 && q.TM == q.TN && q.TM > 1) { q.fold_tm = q.TM; q.TM = (q.fold_tm + 1) / 2; q.TN = q.fold_tm + 1; }
+    static const bool nofold = [] { const char* e = getenv("GPT_GEMM_NOFOLD"); return e && atoi(e) != 0; }();
+    static const int band_min = [] { const char* e = getenv("GPT_GEMM_BAND_MIN"); return e ? atoi(e) : 1 << 30; }();   // diagnostic (unbalanced between XCDs unless T is a multiple of 128): off
+    if (g.lower_only && g.nbatch == 1 && q.TM == q.TN && !g.k_from_ij && q.TM >= band_min) {
+        const int T = q.TM, nbands = (T + 7) / 8;
+        int most = 0;
+        for (int x = 0; x < 8; ++x) {
+            int tot = 0;
+            for (int k = 0; k <= (nbands - 1) / 8; ++k) {
+                const int beta = 8 * k + ((k & 1) ? 7 - x : x);
+                if (beta >= nbands) continue;
+                const int r0 = 8 * beta, nr = T - r0 < 8 ? T - r0 : 8;
+                tot += r0 * nr + nr * (nr + 1) / 2;
+            }
+            if (tot > most) most = tot;
+        }
+        q.fold_tm = -T;
+        q.G = 0;
+        q.nvid = 8 * most;
+        return q;
+    }
+    if (!nofold && g.lower_only && g.nbatch == 1 && q.TM == q.TN && q.TM > 1) { q.fold_tm = q.TM; q.TM = (q.fold_tm + 1) / 2; q.TN = q.fold_tm + 1; }
     q.G = (g.nbatch * q.TM + 7) / 8;            // tile rows (over all batch entries) per XCD
     q.nvid = 8 * q.G * q.TN;
     return q;
 }
 
+// Tile body: 0 = the shipped one (k_gemm); probe builds (-DGPT_GEMM_VARIANTS) also know 1 = two LDS buffers + register
+// staging, 2 = LDS-DMA ring, 3 = two chunks of loads in flight (tools/probes/gemm_bodies.h)
+static int gemm_body() {
+#ifdef GPT_GEMM_VARIANTS
+    static const int v = [] { const char* e = getenv("GPT_GEMM_BODY"); return e ? atoi(e) : 0; }();
+    return v;
+#else
+    return 0;
+#endif
+}
+
+#ifdef GPT_GEMM_VARIANTS      // probe builds: the alternative tile bodies that were measured and not shipped
+#include "../../tools/probes/gemm_bodies.h"
+#endif
+
 template <bool BT, bool AT, int TS>
 static void launch_gemm_ts(hipStream_t s, const GemmArgs& g) {
     const GemmGrid q = gemm_grid(g, TS);
     constexpr size_t lds = (size_t)((AT ? 32 * (TS + 16) : TS * GA_S) + (BT ? TS * GA_S : 32 * (TS + 16))) * sizeof(double);
+#ifdef GPT_GEMM_VARIANTS
+    if constexpr (TS != 32) {
+        if (gemm_body() != 0) { launch_gemm_variant<BT, AT, TS>(s, g, q, lds); return; }
+    }
+#endif
     static PerDeviceOnce once;
     once.run([&] { hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<BT, AT, TS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
     hipLaunchKernelGGL((k_gemm<BT, AT, TS>), dim3(q.nvid), dim3(256), lds, s, g, q.TM, q.TN, q.G, q.fold_tm);
@@ -724,12 +849,24 @@ static int gemm_tile_threshold() {
     return thr;
 }
 
+// 32-tiles below this many 64-tiles: a tile's K loop is a serial chain on ONE CU (a 64-tile of K = 256 lasts 17 us however
+// idle the chip is), so a product with fewer 64-tiles than CUs is bound by that chain; quarter-size tiles cut it by four and
+// put the other CUs to work (the thin updates on the Cholesky's chain, the late trailing updates, everything at N <= 2500)
+static int gemm_tile32_threshold() {
+    static const int thr = [] {
+        const char* e = getenv("GPT_GEMM_TS32_BELOW");
+        return e ? atoi(e) : 1024;      // measured: N = 2500 fit 1.52 -> 1.34 ms, objective 1.85 -> 1.60 ms; 512 .. 2048 equal within noise
+    }();
+    return thr;
+}
+
 template <bool BT, bool AT = false>
 static void launch_gemm(hipStream_t s, const GemmArgs& g) {
     const int Mmax = g.nbatch == 1 ? g.M_last : (g.M > g.M_last ? g.M : g.M_last);
     double tiles = (double)g.nbatch * ((Mmax + 127) / 128) * ((g.N + 127) / 128);
     if (g.lower_only) tiles *= 0.5;
-    if (tiles < gemm_tile_threshold()) launch_gemm_ts<BT, AT, 64>(s, g);
+    if (4.0 * tiles < gemm_tile32_threshold() && gemm_body() == 0) launch_gemm_ts<BT, AT, 32>(s, g);
+    else if (tiles < gemm_tile_threshold()) launch_gemm_ts<BT, AT, 64>(s, g);
     else launch_gemm_ts<BT, AT, 128>(s, g);
 }
 
@@ -767,6 +904,8 @@ static void syrk_update(hipStream_t s, double* K, int NP, int row0, int ncols, i
     c.C = K + (size_t)row0 * NP + row0; c.ldc = NP;
     c.M = c.M_last = rem; c.N = ncols < rem ? ncols : rem; c.K = c.K_last = kw; c.nbatch = 1;
     c.alpha = -1.0; c.beta = 1.0; c.lower_only = 1;
+    static const int stagger = [] { const char* e = getenv("GPT_GEMM_FOLD_INTERLEAVED"); return e && atoi(e) ? -1 : 0; }();
+    c.stagger = stagger;
     launch_gemm<true>(s, c);
 }
 

@@ -25,6 +25,19 @@ int main(int argc, char** argv) {
         hipMemcpy(K, h.data(), bytes, hipMemcpyHostToDevice);
     }
     const int nb = NP / NB, ob = potrf_outer_blocks(), grp = potrf_group(NP), gw = grp * ob;
+    if (argc > 5) {      // single update, repeated: syrk_seq_probe NP reps verbose rem K   (PMC passes)
+        const int rem = atoi(argv[4]), kw = atoi(argv[5]);
+        hipStream_t s1; hipStreamCreate(&s1);
+        hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+        syrk_update(s1, K, NP, NP - rem, rem, NP - rem - kw, kw);
+        hipStreamSynchronize(s1);
+        hipEventRecord(a, s1);
+        for (int r = 0; r < reps; ++r) syrk_update(s1, K, NP, NP - rem, rem, NP - rem - kw, kw);
+        hipEventRecord(b, s1); hipStreamSynchronize(s1);
+        float ms; hipEventElapsedTime(&ms, a, b);
+        printf("single update rem=%d K=%d: %.1f us, %.1f TF\n", rem, kw, ms * 1e3 / reps, (double)rem * (rem + 64) * kw / (ms * 1e-3 / reps) / 1e12);
+        return 0;
+    }
     std::vector<Call> calls;
     for (int g0 = 0; g0 < nb; g0 += gw) {
         const int gend = g0 + gw < nb ? g0 + gw : nb;
