@@ -24,6 +24,7 @@
 #pragma once
 #include <cstdint>
 #include <cstdlib>
+#include <algorithm>
 #include <vector>
 
 namespace gpt {
@@ -96,46 +97,41 @@ inline VarPlanHost build_var_plan(int64_t ncols, int nbi, int ntask, int P, int 
     if (ncb_t == 0) return h;
 
     // ---- the tail's sweeps in execution order
-    struct Sweep { int cbt, task, ib; };
+    // k1 >= 0: only the tiles [0, k1) of this sweep are laid out here; [k1, ib + 1) went to workgroup post_wg (its item
+    // post_idx) as the last partial product of the sweep
+    struct Sweep { int cbt, task, ib; int k1 = -1, post_wg = -1, post_idx = -1; };
     std::vector<Sweep> sweeps;
     sweeps.reserve((size_t)ncb_t * ntask * nbi);
     if (h.order == 0) {
         for (int c = 0; c < ncb_t; ++c)
             for (int t = 0; t < ntask; ++t)
-                for (int ib = nbi - 1; ib >= 0; --ib) sweeps.push_back({c, t, ib});
+                for (int ib = nbi - 1; ib >= 0; --ib) sweeps.push_back(Sweep{c, t, ib});
     } else {
         for (int t = 0; t < ntask; ++t)
             for (int ib = nbi - 1; ib >= 0; --ib)
-                for (int c = 0; c < ncb_t; ++c) sweeps.push_back({c, t, ib});
+                for (int c = 0; c < ncb_t; ++c) sweeps.push_back(Sweep{c, t, ib});
     }
-    int64_t U0 = 0;
-    for (const Sweep& s : sweeps) U0 += var_sweep_cost(s.ib, 0, s.ib + 1);
 
     // ---- cut into P ranges of equal cost at tile granularity
     struct Contribution { bool split; int ref; };                        // ref: item index (flush) or split index
     std::vector<std::vector<Contribution>> contrib;
     std::vector<std::vector<VarItem>> wg;
     constexpr int TOL = VAR_TILE_COST / 2;
-    // Every part of a cut sweep pays the fixed sweep overhead again, so the total to share is only known once the cuts
-    // are: the cut is repeated with the total the previous pass produced (settles after one repetition).
-    auto cut = [&](const int64_t U) -> int64_t {
-        contrib.assign((size_t)ncb_t * ntask, {});
-        wg.assign(P, {});
-        h.splits.clear();
-        h.n_vslots = 0;
+    // lays `sw` end to end over the workgroups [p_begin, p_begin + Pn) in Pn ranges of equal cost; U = total cost to share
+    auto cut_range = [&](const std::vector<Sweep>& sw, const int p_begin, const int Pn, const int64_t U) -> int64_t {
         int p = 0;
         int64_t cum = 0;
-        auto boundary = [&](int q) { return U / P * (q + 1) + (U % P) * (q + 1) / P; };
+        auto boundary = [&](int q) { return U / Pn * (q + 1) + (U % Pn) * (q + 1) / Pn; };
         std::vector<std::pair<int, int>> parts;                          // (workgroup, index in wg[workgroup]) of the current sweep
-        for (const Sweep& s : sweeps) {
+        for (const Sweep& s : sw) {
             parts.clear();
             int k = 0;
-            const int kend = s.ib + 1;
+            const int kend = s.k1 >= 0 ? s.k1 : s.ib + 1;
             while (k < kend) {
                 const int rem = var_sweep_cost(s.ib, k, kend);
                 const int64_t room = boundary(p) - cum;
                 int take = kend - k;
-                if (p < P - 1 && rem > room + TOL) {
+                if (p < Pn - 1 && rem > room + TOL) {
                     // tiles that fit into what is left of this workgroup's share (full tiles come first, the diagonal last)
                     int64_t nt = (room - VAR_SWEEP_OVERHEAD + TOL) / VAR_TILE_COST;
                     if (nt > kend - k - 1) nt = kend - k - 1;            // leave something for the next workgroup
@@ -143,12 +139,13 @@ inline VarPlanHost build_var_plan(int64_t ncols, int nbi, int ntask, int P, int 
                     take = (int)nt;
                 }
                 VarItem it{(int)d.nfull + s.cbt, s.task, s.ib, k, k + take, 0, -1, -1};
-                parts.emplace_back(p, (int)wg[p].size());
-                wg[p].push_back(it);
+                parts.emplace_back(p_begin + p, (int)wg[p_begin + p].size());
+                wg[p_begin + p].push_back(it);
                 cum += var_sweep_cost(s.ib, k, k + take);
                 k += take;
                 if (k < kend) ++p;                                       // the rest of this sweep belongs to the next one
             }
+            if (s.post_wg >= 0) parts.emplace_back(s.post_wg, s.post_idx);
             if (parts.size() > 1) {                                      // cut: every part is a partial product
                 VarSplit sp{(int)h.n_vslots, (int)(h.n_vslots + (int64_t)parts.size()), -1};
                 for (auto& pr : parts) wg[pr.first][pr.second].vslot = (int)h.n_vslots++;
@@ -158,11 +155,85 @@ inline VarPlanHost build_var_plan(int64_t ncols, int nbi, int ntask, int P, int 
         }
         return cum;
     };
-    int64_t U = cut(U0);
-    for (int rep = 0; rep < 3; ++rep) {
-        const int64_t U2 = cut(U);
-        if (U2 == U) break;
-        U = U2;
+    auto reset = [&]() {
+        contrib.assign((size_t)ncb_t * ntask, {});
+        wg.assign(P, {});
+        h.splits.clear();
+        h.n_vslots = 0;
+    };
+    // Every part of a cut sweep pays the fixed sweep overhead again, so the total to share is only known once the cuts
+    // are: the cut is repeated with the total the previous pass produced (settles after one repetition).
+    auto cut_settled = [&](std::vector<Sweep>& sw, const int p_begin, const int Pn, auto&& before_each) {
+        int64_t U = 0;
+        for (const Sweep& x : sw) U += var_sweep_cost(x.ib, 0, x.k1 >= 0 ? x.k1 : x.ib + 1);
+        for (int rep = 0; rep < 4; ++rep) {
+            reset();
+            before_each();                       // (may set the k0 / pre_* fields of sw: the U of the first pass is then an over-estimate, corrected by the repetition)
+            const int64_t U2 = cut_range(sw, p_begin, Pn, U);
+            if (U2 == U) break;
+            U = U2;
+        }
+    };
+
+    // ---- Cohorts (block-major order, at least half as many blocks as workgroups, i.e. no block can have two workgroups of
+    // its own): workgroup b < ncb_t takes the long sweeps ib = nbi-1 .. s of block b WHOLE — those workgroups start together
+    // and do the same work, so they walk the tiles of A in step and an XCD's 32 of them share one copy of that stream in
+    // L2, as in the rounds — and the other P - ncb_t workgroups share the short sweeps ib < s of all blocks, cut at tile
+    // granularity as below.  s balances the two cohorts.  Why: laid end to end, every workgroup is at a different tile
+    // of A at any time and nothing of that stream is shared: at N = 8192, M = 10^4 (157 blocks on 256 workgroups) the launch
+    // pulled 157 x 285 MB = 45 GB through L2 in 10.6 ms and ran at the HBM rate, 80 % of its MFMA floor
+    // (profiles/r02_small_m.log); the short sweeps only touch the first s (s + 1) / 2 tiles of every task (110 MB at s = 10).
+    // Used when ONE boundary s balances the cohorts to 4 % (many i-blocks: N >= 4096 or so); with few i-blocks the list cut
+    // tile by tile below balances better and the factor is small enough to stay in cache anyway.
+    bool cohorts = h.order == 0 && 2 * ncb_t >= P && ncb_t < P && nbi >= 2;
+    const int nB = P - ncb_t;
+    // The long cohort also takes the LAST best_f tiles (the diagonal one included) of sweep best_s - 1, as a partial product:
+    // what balances the two cohorts to a tile.  The short cohort runs its part [0, best_s - best_f) of that sweep after
+    // sweep best_s - 2, whose generating pass has produced every kernel column the part needs.
+    int best_s = 1, best_f = 0;
+    if (cohorts) {
+        int64_t best = -1, all = 0;
+        for (int ib = 0; ib < nbi; ++ib) all += var_sweep_cost(ib, 0, ib + 1);
+        for (int s = 1; s < nbi; ++s)
+            for (int f = 0; f < s; ++f) {
+                if (f > 0 && s < 2) continue;                         // the short cohort's part needs a sweep in front of it
+                int64_t a = f ? var_sweep_cost(s - 1, s - f, s) : 0, b = var_sweep_cost(s - 1, 0, s - f);
+                for (int ib = 0; ib < nbi; ++ib)
+                    if (ib >= s) a += var_sweep_cost(ib, 0, ib + 1);
+                    else if (ib < s - 1) b += var_sweep_cost(ib, 0, ib + 1);
+                a *= ntask; b *= ntask;
+                const int64_t span = std::max<int64_t>(a, (b * ncb_t + nB - 1) / nB);
+                if (best < 0 || span < best) { best = span; best_s = s; best_f = f; }
+            }
+        const int64_t ideal = (all * ntask * ncb_t + P - 1) / P;
+        cohorts = 100 * best <= 104 * ideal;
+    }
+    if (cohorts) {
+        std::vector<Sweep> shortsw;
+        shortsw.reserve((size_t)ncb_t * ntask * best_s);
+        std::vector<size_t> cut_at((size_t)ncb_t * ntask, 0);             // index in shortsw of the (c, t, best_s - 1) entry
+        for (int c = 0; c < ncb_t; ++c)
+            for (int t = 0; t < ntask; ++t) {
+                // order: best_s - 2 (generates tiles [0, best_s - 1)), then the part of best_s - 1, then the rest, longest first
+                if (best_s >= 2 && best_f > 0) shortsw.push_back(Sweep{c, t, best_s - 2});
+                cut_at[(size_t)c * ntask + t] = shortsw.size();
+                shortsw.push_back(Sweep{c, t, best_s - 1});
+                for (int ib = best_s - 2 - ((best_s >= 2 && best_f > 0) ? 1 : 0); ib >= 0; --ib) shortsw.push_back(Sweep{c, t, ib});
+            }
+        cut_settled(shortsw, ncb_t, nB, [&]() {
+            for (int c = 0; c < ncb_t; ++c)
+                for (int t = 0; t < ntask; ++t) {
+                    for (int ib = nbi - 1; ib >= best_s; --ib)
+                        wg[c].push_back(VarItem{(int)d.nfull + c, t, ib, 0, ib + 1, 0, -1, -1});
+                    if (best_f > 0) {
+                        Sweep& sp = shortsw[cut_at[(size_t)c * ntask + t]];
+                        sp.k1 = best_s - best_f; sp.post_wg = c; sp.post_idx = (int)wg[c].size();
+                        wg[c].push_back(VarItem{(int)d.nfull + c, t, best_s - 1, best_s - best_f, best_s, 0, -1, -1});
+                    }
+                }
+        });
+    } else {
+        cut_settled(sweeps, 0, P, []() {});
     }
 
     // ---- flags and flush groups per workgroup; items concatenated in workgroup order

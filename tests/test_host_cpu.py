@@ -339,13 +339,46 @@ def _check_var_plan(cols, nbi, nt, P, order):
 
 @pytest.mark.parametrize("cols,nbi,nt,P", [(64, 1, 1, 256), (460, 5, 1, 256), (1000, 16, 1, 256), (4 * 4096, 16, 1, 256),
                                            (500_000, 16, 1, 256), (4 * 500_000, 16, 1, 256), (4_000_000, 4, 3, 256),
-                                           (3 * 700, 2, 3, 256), (300, 3, 2, 7), (16384, 16, 1, 256), (16384 + 64, 16, 1, 256)])
+                                           (3 * 700, 2, 3, 256), (300, 3, 2, 7), (16384, 16, 1, 256), (16384 + 64, 16, 1, 256),
+                                           (10_000, 16, 1, 256), (4 * 10_000 // 3, 16, 1, 256), (133 * 64, 16, 1, 256), (250 * 64, 16, 1, 256),
+                                           (128 * 64, 5, 1, 256), (200 * 64, 4, 3, 256), (5 * 64, 2, 1, 7), (500_000, 16, 1, 256)])
 @pytest.mark.parametrize("order", [-1, 0, 1])
 def test_variance_work_plan_is_a_partition(cols, nbi, nt, P, order):
     pl, cost = _check_var_plan(cols, nbi, nt, P, order)
     busy = cost[cost > 0]
-    if len(busy) == P and pl["nfull"] == 0:               # every workgroup has work: shares within a tile of each other
-        assert busy.max() - busy.min() <= 2 * 128 + 72
+    ncb_t = pl["ncb"] - pl["nfull"]
+    if len(busy) == P and pl["nfull"] == 0:               # every workgroup has work
+        # one list cut at tile granularity: shares within a tile of each other; or two cohorts (whole long sweeps | cut short
+        # sweeps), balanced by the choice of ONE i-block boundary and only used when that balances to a few per cent
+        assert (busy.max() - busy.min() <= 2 * 128 + 72 or (order <= 0 and 2 * ncb_t >= P and busy.max() <= 1.06 * busy.mean())
+                or (order == 1 and busy.max() <= 1.06 * busy.mean()))        # (sweep-major diagnostic order: overheads of many cuts)
+
+
+def test_variance_work_plan_cohorts_keep_the_long_sweeps_whole():
+    """128 .. 255 column blocks on 256 workgroups (the reference's 10^4-point grids at N = 8192; the tail of the benchmark's
+    launch): workgroup b takes the long sweeps of block b whole and in the same order as every other workgroup of that
+    cohort (they walk the inverse factor in step), the short sweeps are shared by the remaining workgroups."""
+    from gaussian_process_transportation_amd import _lib
+    for cols, nbi in ((10_000, 16), (133 * 64, 16), (250 * 64, 16), (200 * 64, 16)):
+        pl = _lib.debug_var_plan(cols, nbi, 1, 256, -1)
+        ncb = pl["ncb"]
+        ib_ = pl["item_begin"]
+        first = [pl["items"][ib_[p]:ib_[p + 1]] for p in range(ncb)]
+        whole0 = [it for it in first[0] if int(it[7]) < 0]
+        s = min(int(it[2]) for it in whole0)
+        for b, items in enumerate(first):
+            assert [int(it[0]) for it in items] == [b] * len(items)
+            whole = [it for it in items if int(it[7]) < 0]
+            part = [it for it in items if int(it[7]) >= 0]
+            assert [int(it[2]) for it in whole] == list(range(nbi - 1, s - 1, -1))          # ib = nbi-1 .. s, whole
+            assert all(int(it[3]) == 0 and int(it[4]) == int(it[2]) + 1 for it in whole)
+            # at most one partial product, the LAST tiles of the next shorter sweep (what balances the two cohorts), the
+            # same for every block
+            assert len(part) <= 1 and all(int(it[2]) == s - 1 and int(it[3]) >= 1 and int(it[4]) == s for it in part)      # ... up to the diagonal
+            assert [tuple(int(v) for v in it[2:5]) for it in part] == [tuple(int(v) for v in it[2:5]) for it in first[0] if int(it[7]) >= 0]
+        rest = pl["items"][ib_[ncb]:]
+        assert len(rest) and max(int(it[2]) for it in rest) == s - 1
+        _check_var_plan(cols, nbi, 1, 256, -1)
 
 
 def test_variance_work_plan_random_shapes():
