@@ -550,7 +550,7 @@ __device__ __forceinline__ double lds_ld(const double* p) {
 // triangular, grows with ti when A is, shrinks with ti for W^T W), and the ~64 workgroups it runs at a time share
 // a few row and column panels in that XCD's L2.
 #ifndef GPT_GEMM_ABL       // timing-only ablation builds of k_gemm (tools/probes/syrk_seq_probe.hip): 1 no operand loads, 2 no LDS stores,
-#define GPT_GEMM_ABL 0     // 3 no C traffic, 4 no C store, 5 no MFMAs.  Results are wrong unless 0.
+#define GPT_GEMM_ABL 0     // 3 no C traffic, 4 no C store, 5 no MFMAs, 6 no barriers.  Results are wrong unless 0.
 #endif
 #ifdef GPT_GEMM_TRACE      // tools/probes/gemm_tile_trace.hip: shader-clock stamps of the phases of one tile (diagnostic builds only)
 __device__ long long* g_gemm_trace = nullptr;
@@ -724,7 +724,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int TM, int TN, int
     for (int kc = kbeg; kc < kend; kc += 32) {
         stage();
         GPT_GT(2 + 3 * ((kc - kbeg) / 32));
-        __syncthreads();
+        if (GPT_GEMM_ABL != 6) __syncthreads();
         if (kc + 32 < kend) fetch(kc + 32);
         GPT_GT(3 + 3 * ((kc - kbeg) / 32));
         if (active) {
@@ -749,7 +749,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int TM, int TN, int
             }
         }
         GPT_GT(4 + 3 * ((kc - kbeg) / 32));
-        __syncthreads();
+        if (GPT_GEMM_ABL != 6) __syncthreads();
     }
     GPT_GT(60);
     if (!active) return;

@@ -10,7 +10,7 @@ rocprofv3 -L > "$OUT/counters_list.txt" 2>&1
 pass() {  # name, counters...
     local name=$1; shift
     echo "=== pmc pass $name: $*"
-    timeout -k 10 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$OUT/$name" -o pmc -- python3 bench.py --steps 1 --warmup 0 --cpu-sample 0 ${BENCH_ARGS:-} > "$OUT/$name.log" 2>&1
+    timeout -k 10 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$OUT/$name" -o pmc -- python3 bench.py --steps 1 --warmup 0 --cpu-sample 0 --no-secondary ${BENCH_ARGS:-} > "$OUT/$name.log" 2>&1
     local rc=$?
     echo "rc=$rc" >> "$OUT/$name.log"
     if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "pass $name timed out: stopping"; exit $rc; fi

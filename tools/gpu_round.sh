@@ -24,7 +24,7 @@ run_step bench 400 python bench.py "$@"
 tail -n 3 "$OUT/bench.log"
 if [ "${SKIP_PROF:-0}" != "1" ]; then
     export TMPDIR=/tmp
-    run_step rocprof 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o trace -- python3 bench.py --steps 2 --warmup 1 --cpu-sample 0 "$@"
+    run_step rocprof 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o trace -- python3 bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-secondary "$@"
     find "$OUT/prof" -name "*kernel_stats*.csv" | head -1 | xargs -r head -n 20
     # keep only the small summaries (the per-dispatch trace can be large)
     find "$OUT/prof" -name "*kernel_trace*.csv" -size +2M -delete
