@@ -11,6 +11,13 @@ from tests.conftest import assert_parity, load_golden
 pytestmark = pytest.mark.gpu
 
 RTOL = 1e-5
+# Optimizer-on comparisons: the same L-BFGS-B driver fed objective values that agree to rounding takes the same steps, so the
+# fitted hyper-parameters agree far better than an optimiser's tolerance suggests.  Bounds ~ 100 x the values measured in
+# round 3 (printed by the tests; round 2 allowed 1e-3 everywhere): theta 1.4e-13 (surface-3D), 6.1e-13 (Matern dynamics GP),
+# 2.7e-7 (6-D, 3 runs on noisy data), 1.4e-7 (surface-3D example: its dynamics GP is fitted on the transported demo);
+# outputs 5e-14 .. 3e-12 (surface-3D, Matern), 4e-12 / 1.4e-11 (letter-S example), 8e-9 / 6.5e-8 (surface-3D example).
+THETA_TOL = {"surface3d": 1e-9, "sixd": 1e-5, "matern": 1e-9, "surface3d_example": 1e-5}
+OUT_TOL = {"surface3d": 1e-9, "matern": 1e-9, "letterS_example": 1e-8, "surface3d_example": 1e-5}
 
 
 def sk_kernel(c, ls, noise):
@@ -282,7 +289,9 @@ def test_gaussian_process_class_in_six_dimensions_matches_sklearn_after_optimisa
     np.random.seed(3)
     gp = GaussianProcess(kernel=k0, alpha=1e-10, n_restarts_optimizer=2, verbose=False).fit(X, Y)
     assert gp.gp.log_marginal_likelihood_value_ == pytest.approx(ref.log_marginal_likelihood_value_, rel=1e-6)
-    assert_parity(gp.gp.kernel_.theta, ref.kernel_.theta, 1e-3, "fitted theta")
+    from tests.conftest import relmax
+    print(f"6-D optimizer: theta vs sklearn {relmax(gp.gp.kernel_.theta, ref.kernel_.theta):.2e}")
+    assert_parity(gp.gp.kernel_.theta, ref.kernel_.theta, THETA_TOL["sixd"], "fitted theta")
     Xq = rng.uniform(0, 1, (500, D))
     fixed = GaussianProcess(kernel=ref.kernel_, alpha=1e-10, optimizer=None, verbose=False).fit(X, Y)
     m_ref, s_ref = ref.predict(Xq, return_std=True)
@@ -538,7 +547,22 @@ def test_surface3d_with_optimizer_reaches_reference_optimum():
     lml_ref = float(g["lml_fit"])
     print(f"surface-3D optimizer: LML {gp.gp.log_marginal_likelihood_value_!r} vs sklearn {lml_ref!r}")
     assert gp.gp.log_marginal_likelihood_value_ >= lml_ref - 1e-8 * abs(lml_ref)
-    assert_parity(np.asarray(gp.kernel.theta), g["theta_fit"], 1e-3, "fitted theta")
+    from tests.conftest import relmax
+    print(f"surface-3D optimizer: theta vs sklearn {relmax(np.asarray(gp.kernel.theta), g['theta_fit']):.2e}")
+    assert_parity(np.asarray(gp.kernel.theta), g["theta_fit"], THETA_TOL["surface3d"], "fitted theta")
+    # and the predictions at the GPU's theta against the golden ones (the reference's, at ITS theta): within what the theta
+    # difference explains (the same GPU path at the reference's theta) + 1e-5, as for letter-S
+    m, s = gp.predict(aff.predict(g["demo"]), return_std=True)
+    fixed = GaussianProcess(kernel=sk_kernel(g["constant_value"], g["length_scale"], g["noise_level"]), optimizer=None, verbose=False)
+    fixed.fit(src, g["target"] - src)
+    m0, s0 = fixed.predict(aff.predict(g["demo"]), return_std=True)
+    for name, got, at_ref, ref in (("traj", aff.predict(g["demo"]) + m, aff.predict(g["demo"]) + m0, g["traj"]), ("std", s, s0, g["std"])):
+        scale = np.max(np.abs(ref))
+        explained = np.max(np.abs(got - at_ref)) / scale
+        err = np.max(np.abs(got - ref)) / scale
+        print(f"surface-3D optimizer {name}: vs golden {err:.2e}, explained by theta {explained:.2e}")
+        assert err <= explained + 1e-5, (name, err, explained)
+        assert err <= OUT_TOL["surface3d"], (name, err)
 
 
 @pytest.mark.parametrize("N,M", [(1024, 150_000), (2500, 70_000)])
@@ -729,10 +753,21 @@ def test_matern_dynamics_gp_with_optimizer():
     gp = GaussianProcess(kernel=C(constant_value=np.sqrt(0.1)) * Matern(1 * np.ones(2), nu=2.5) + WhiteKernel(0.01), verbose=False)
     gp.fit(g["X"], g["Y"])
     assert gp.gp.log_marginal_likelihood_value_ == pytest.approx(float(g["opt_lml"]), rel=1e-6)
-    assert_parity(np.asarray(gp.kernel.theta), g["opt_theta"], 1e-3, "fitted theta")
+    from tests.conftest import relmax
+    print(f"Matern dynamics optimizer: theta vs sklearn {relmax(np.asarray(gp.kernel.theta), g['opt_theta']):.2e}")
+    assert_parity(np.asarray(gp.kernel.theta), g["opt_theta"], THETA_TOL["matern"], "fitted theta")
     m, s = gp.predict(g["grid"], return_std=True)
-    assert_parity(m, g["opt_mean"], 1e-3, "mean")
-    assert_parity(s, g["opt_std"], 1e-3, "std")
+    th = g["opt_theta"]
+    fixed = GaussianProcess(kernel=C(np.exp(th[0])) * Matern(np.exp(th[1:3]), nu=2.5) + WhiteKernel(np.exp(th[3])), optimizer=None, verbose=False)
+    fixed.fit(g["X"], g["Y"])
+    m0, s0 = fixed.predict(g["grid"], return_std=True)
+    for name, got, at_ref, ref in (("mean", m, m0, g["opt_mean"]), ("std", s, s0, g["opt_std"])):
+        scale = np.max(np.abs(ref))
+        explained = np.max(np.abs(got - at_ref)) / scale
+        err = np.max(np.abs(got - ref)) / scale
+        print(f"Matern dynamics optimizer {name}: vs golden {err:.2e}, explained by theta {explained:.2e}")
+        assert err <= explained + 1e-5, (name, err, explained)
+        assert err <= OUT_TOL["matern"], (name, err)
 
 
 def test_letter_s_example_end_to_end():
@@ -746,8 +781,10 @@ def test_letter_s_example_end_to_end():
     spec.loader.exec_module(mod)
     out = mod.main(verbose=False)
     g = load_golden("letterS_2d")
-    assert_parity(out["X1"], g["traj"], 1e-3, "transported demo")
-    assert_parity(out["deltaX1"], g["vel"], 1e-3, "transported velocities")
+    from tests.conftest import relmax
+    print(f"letter-S example: traj {relmax(out['X1'], g['traj']):.2e}, vel {relmax(out['deltaX1'], g['vel']):.2e}")
+    assert_parity(out["X1"], g["traj"], OUT_TOL["letterS_example"], "transported demo")
+    assert_parity(out["deltaX1"], g["vel"], OUT_TOL["letterS_example"], "transported velocities")
     assert out["field"].shape == (10000, 2) and np.all(np.isfinite(out["field1"]))
 
 
@@ -793,9 +830,12 @@ def test_surface_3d_example_end_to_end():
     spec.loader.exec_module(mod)
     out = mod.main(verbose=False)
     g = load_golden("surface_3d")
-    assert_parity(out["theta"], g["theta_fit"], 1e-3, "fitted theta")
-    assert_parity(out["X1"], g["traj"], 1e-4, "transported demo")
-    assert_parity(out["deltaX1"], g["vel"], 1e-3, "transported velocities")
+    from tests.conftest import relmax
+    print(f"surface-3D example: theta {relmax(out['theta'], g['theta_fit']):.2e}, traj {relmax(out['X1'], g['traj']):.2e}, "
+          f"vel {relmax(out['deltaX1'], g['vel']):.2e}")
+    assert_parity(out["theta"], g["theta_fit"], THETA_TOL["surface3d_example"], "fitted theta")
+    assert_parity(out["X1"], g["traj"], 1e-6, "transported demo")
+    assert_parity(out["deltaX1"], g["vel"], OUT_TOL["surface3d_example"], "transported velocities")
 
 
 def test_prefetch_changes_nothing_but_the_number_of_passes():
