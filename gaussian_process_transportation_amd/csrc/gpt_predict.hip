@@ -190,7 +190,10 @@ __global__ __launch_bounds__(256) void k_mean_jac(KernelParams p, const T* __res
 template <typename T, int DW>
 static void launch_mean_jac_t(hipStream_t s, const KernelParams& p, const T* Xs, const T* A4,
                               const T* Xq, int64_t M, T* mean, T* J) {
-    constexpr int QPW = DW == 3 ? 2 : 1;
+#ifndef GPT_MJ_QPW
+#define GPT_MJ_QPW 2
+#endif
+    constexpr int QPW = DW == 3 ? GPT_MJ_QPW : 1;          // queries per wave; 500k queries at N = 8192: 1 -> 9.17 ms, 2 -> 6.19-6.26, 4 -> 6.11 (r3mj)
     const int64_t waves = (M + QPW - 1) / QPW;
     const int64_t blocks = (waves + 3) / 4;
     for (int ob = 0; ob < p.O; ob += 4) {
