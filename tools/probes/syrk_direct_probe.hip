@@ -82,20 +82,21 @@ __global__ __launch_bounds__(256, OCC) void k_syrk_direct(double* __restrict__ C
 }
 
 template <int NST, int KB, int OCC, bool TILED = false>
-static float run(hipStream_t s, double* K, int NP, int rem, int kw, int reps) {
+static float run(hipStream_t s, double* K, int NP, int rem, int kw, int reps, int ld = 0) {
     const int T = rem / 128, ntiles = T * (T + 1) / 2;
-    double* C = K + (size_t)(NP - rem) * NP + (NP - rem);
-    const double* P = K + (size_t)(NP - rem) * NP + (NP - rem - kw);
+    if (!ld) ld = NP;
+    double* C = K + (size_t)(NP - rem) * ld + (NP - rem);
+    const double* P = K + (size_t)(NP - rem) * ld + (NP - rem - kw);
     if (TILED) {
         const size_t tr = (size_t)(NP / 64) * 4096;
         C = K + (size_t)((NP - rem) / 64) * tr + (size_t)((NP - rem) / 64) * 4096;
         P = K + (size_t)((NP - rem) / 64) * tr + (size_t)((NP - rem - kw) / 64) * 4096;
     }
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    hipLaunchKernelGGL((k_syrk_direct<NST, KB, OCC, TILED>), dim3(ntiles), dim3(256), 0, s, C, P, NP, T);
+    hipLaunchKernelGGL((k_syrk_direct<NST, KB, OCC, TILED>), dim3(ntiles), dim3(256), 0, s, C, P, ld, T);
     hipStreamSynchronize(s);
     hipEventRecord(a, s);
-    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((k_syrk_direct<NST, KB, OCC, TILED>), dim3(ntiles), dim3(256), 0, s, C, P, NP, T);
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((k_syrk_direct<NST, KB, OCC, TILED>), dim3(ntiles), dim3(256), 0, s, C, P, ld, T);
     hipEventRecord(b, s); hipStreamSynchronize(s);
     float ms; hipEventElapsedTime(&ms, a, b);
     return ms * 1e3f / reps;
@@ -109,7 +110,7 @@ int main(int argc, char** argv) {
     if (rem % 128 || kw != 256 || rem + kw > NP) { printf("rem must be a multiple of 128, K = 256\n"); return 1; }
     const size_t bytes = (size_t)NP * NP * sizeof(double);
     double *K1, *K2;
-    hipMalloc(&K1, bytes); hipMalloc(&K2, bytes);
+    hipMalloc(&K1, bytes); hipMalloc(&K2, bytes + (size_t)NP * 1024);       // room for a padded row pitch
     std::vector<double> h((size_t)NP * NP);
     unsigned sd = 12345;
     for (auto& v : h) { sd = sd * 1664525u + 1013904223u; v = ((sd >> 8) & 0xffff) / 65536.0 * 1e-3; }
@@ -150,6 +151,27 @@ int main(int argc, char** argv) {
     report("direct, 1 block ahead, 1 WG/CU", run<2, 32, 1>(s, K2, NP, rem, kw, reps));
     report("direct, 2 blocks ahead, 1 WG/CU", run<3, 32, 1>(s, K2, NP, rem, kw, reps));
     report("direct, 3 blocks ahead, 1 WG/CU", run<4, 32, 1>(s, K2, NP, rem, kw, reps));
+    // the same row-major matrix with a row pitch that is NOT a multiple of 4 KiB: rows of a tile then spread over the L2 channels
+    for (int pad : {16, 32, 64}) {
+        char name[64];
+        snprintf(name, sizeof name, "direct, 1 ahead, 1 WG/CU, ld+%d", pad);
+        report(name, run<2, 32, 1>(s, K2, NP, rem, kw, reps, NP + pad));
+        snprintf(name, sizeof name, "direct, 1 ahead, 2 WG/CU, ld+%d", pad);
+        report(name, run<2, 32, 2>(s, K2, NP, rem, kw, reps, NP + pad));
+        GemmArgs c{};
+        const int ld = NP + pad;
+        c.A = K2 + (size_t)(NP - rem) * ld + (NP - rem - kw); c.lda = ld; c.B = c.A; c.ldb = ld;
+        c.C = K2 + (size_t)(NP - rem) * ld + (NP - rem); c.ldc = ld;
+        c.M = c.M_last = rem; c.N = rem; c.K = c.K_last = kw; c.nbatch = 1; c.alpha = -1.0; c.beta = 1.0; c.lower_only = 1;
+        launch_gemm<true>(s, c); hipStreamSynchronize(s);
+        hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+        hipEventRecord(a, s);
+        for (int r = 0; r < reps; ++r) launch_gemm<true>(s, c);
+        hipEventRecord(b, s); hipStreamSynchronize(s);
+        float ms; hipEventElapsedTime(&ms, a, b);
+        snprintf(name, sizeof name, "k_gemm, ld+%d", pad);
+        report(name, ms * 1e3f / reps);
+    }
     report("tiled layout, 1 ahead, 2 WG/CU", run<2, 32, 2, true>(s, K2, NP, rem, kw, reps));
     report("tiled layout, 1 ahead, 1 WG/CU", run<2, 32, 1, true>(s, K2, NP, rem, kw, reps));
     report("tiled layout, 2 ahead, 1 WG/CU", run<3, 32, 1, true>(s, K2, NP, rem, kw, reps));
