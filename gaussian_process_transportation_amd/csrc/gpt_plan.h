@@ -61,6 +61,10 @@ struct VarPlanDev {
     const VarItem* items;
     const int* fin;             // [(ncb - nfull) * ntask][2]: slab slot range of a tail (block, task)
     const VarSplit* splits;
+    // the part of the plan ONE launch of k_var executes (set per launch by launch_var: the rounds are dealt to several
+    // launches so that the workgroups start each stretch of rounds together; the item list goes with the last one)
+    int64_t rnd_begin = 0, rnd_end = 0;
+    int with_tail = 1;
 };
 
 struct VarPlanHost {

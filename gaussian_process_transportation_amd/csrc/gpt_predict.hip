@@ -344,9 +344,8 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
     // this workgroup's B image: k-step s, lane l at s*64 + l (v4 units)
     v4* const buni = reinterpret_cast<v4*>(bscratch) + (size_t)blockIdx.x * ((size_t)p.NP * 16);
 
-    const int64_t rounds = pl.nfull / pl.P;
     const int per_block = pl.ntask * nbi;                       // sweeps of a whole block
-    const int64_t n_implicit = rounds * per_block;
+    const int64_t n_implicit = (pl.rnd_end - pl.rnd_begin) * per_block;     // this launch's rounds
     const int it_begin = pl.item_begin[blockIdx.x], it_end = pl.item_begin[blockIdx.x + 1];
 
     T ssq[4] = {0, 0, 0, 0}, crs[4] = {0, 0, 0, 0};
@@ -354,8 +353,9 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
         // ---- next item: derived (rounds of whole blocks, in step with every other workgroup) or listed (tail)
         int64_t cb; int task, ib, k_lo, k_hi, flags, slot, vslot;
         if (it < n_implicit) {
-            const int64_t rnd = it / per_block;
-            const int r = (int)(it - rnd * per_block);
+            const int64_t rl = it / per_block;
+            const int r = (int)(it - rl * per_block);
+            const int64_t rnd = pl.rnd_begin + rl;
             task = r / nbi;
             ib = nbi - 1 - (r - task * nbi);
             cb = rnd * pl.P + blockIdx.x;
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
             vslot = -1;
         } else {
             const int64_t idx = it_begin + (it - n_implicit);
-            if (idx >= it_end) break;
+            if (!pl.with_tail || idx >= it_end) break;
             const VarItem item = pl.items[idx];
             cb = item.cb; task = item.task; ib = item.ib; k_lo = item.k_lo; k_hi = item.k_hi;
             flags = item.flags; slot = item.slot; vslot = item.vslot;
@@ -808,17 +808,37 @@ static void var_kernel_setup() {
     });
 }
 
+// rounds of whole column blocks per launch of k_var (0: all in one launch); see launch_var_t
+static int var_rounds_per_launch() {
+    static const int v = [] { const char* e = getenv("GPT_VAR_ROUNDS_PER_LAUNCH"); return e ? atoi(e) : 16; }();
+    return v;
+}
+
 template <typename T>
 static void launch_var_t(hipStream_t s, const KernelParams& p, const VarWorkspace& ws, const T* Xs, const T* Wf,
                          const T* Xq, int64_t M, int ncomp, T* var, T* Jvar, T* dvar, const double* hdr) {
-    const VarPlanDev& pl = ws.plan->d;
+    const VarPlanDev& pl_all = ws.plan->d;
     constexpr size_t lds = var_lds_bytes<T>();
     var_kernel_setup<T>();
     T* slab = static_cast<T*>(ws.slab);
     T* vslab = static_cast<T*>(ws.vslab);
     T* bscr = static_cast<T*>(ws.bscratch);
-    const dim3 grid((unsigned)pl.P), fgrid((unsigned)pl.ncb), cgrid((unsigned)pl.n_splits);
+    const dim3 grid((unsigned)pl_all.P), fgrid((unsigned)pl_all.ncb), cgrid((unsigned)pl_all.n_splits);
     const bool wide = p.D > 3;
+    const bool cross = ncomp >= 4 && dvar != nullptr;
+    // The persistent workgroups are not synchronised between rounds and drift apart; once they are further apart than a W
+    // tile stays in L2 each fetches its own copy of the W stream (mode J+Jvar, 122 rounds in one launch: 155 MB fetched per
+    // column block against 68 MB for the same kernel over 31 rounds, L2 hit rate 54 % against 78 %).  A kernel boundary is the
+    // one barrier that needs no co-residency: the rounds go out `var_rounds_per_launch()` at a time.  16 per launch: the same
+    // run time (269.9-270.5 k/s in one launch, 270.9-271.3 k/s at 8-16), HBM-side bytes 4.99 -> 1.40 TB per 500k queries,
+    // L2 hit rate 54 -> 86 % (profiles/r03_kvar_round_drift.txt).
+    const int64_t rounds = pl_all.nfull / pl_all.P;
+    const int64_t rpl = var_rounds_per_launch() > 0 ? var_rounds_per_launch() : (rounds > 0 ? rounds : 1);
+    for (int64_t r0 = 0; r0 == 0 || r0 < rounds; r0 += rpl) {
+    VarPlanDev pl = pl_all;
+    pl.rnd_begin = r0;
+    pl.rnd_end = r0 + rpl < rounds ? r0 + rpl : rounds;
+    pl.with_tail = pl.rnd_end >= rounds ? 1 : 0;
 #define GPT_KVAR(NC_, CR_, KT_, DW_) hipLaunchKernelGGL((k_var<T, NC_, CR_, KT_, DW_>), grid, dim3(512), lds, s, p, pl, Xs, Wf, Xq, M, slab, vslab, bscr)
 #define GPT_KVAR1(DW_)                                                  \
         switch (p.ktype) {                                               \
@@ -827,7 +847,6 @@ static void launch_var_t(hipStream_t s, const KernelParams& p, const VarWorkspac
             case KT_MATERN52: GPT_KVAR(1, false, KT_MATERN52, DW_); break; \
             default: GPT_KVAR(1, false, KT_RBF, DW_);                    \
         }
-    const bool cross = ncomp >= 4 && dvar != nullptr;
     if (ncomp == VAR_NCOMP_DERIV4) {          // D = 4, Jacobian variance alone: dk_0 .. dk_3
         hipLaunchKernelGGL((k_var<T, 4, false, KT_RBF, MAX_D, false>), grid, dim3(512), lds, s, p, pl, Xs, Wf, Xq, M, slab, vslab, bscr);
     } else if (ncomp == VAR_NCOMP_DERIV8) {   // D = 8
@@ -846,8 +865,10 @@ static void launch_var_t(hipStream_t s, const KernelParams& p, const VarWorkspac
         if (cross) GPT_KVAR(16, true, KT_RBF, MAX_D);
         else GPT_KVAR(16, false, KT_RBF, MAX_D);
     }
+    }
 #undef GPT_KVAR1
 #undef GPT_KVAR
+    const VarPlanDev& pl = pl_all;
     if (pl.n_splits > 0) {
         if (!cross) hipLaunchKernelGGL((k_var_combine<T, false>), cgrid, dim3(512), 0, s, pl, vslab, slab);
         else if (ncomp == 4) hipLaunchKernelGGL((k_var_combine<T, true, 4>), cgrid, dim3(512), 0, s, pl, vslab, slab);

@@ -6,7 +6,7 @@ plus elementwise rtol/atol (tests/conftest.py:assert_parity)."""
 import numpy as np
 import pytest
 
-from tests.conftest import assert_parity, load_golden
+from tests.conftest import assert_parity, load_golden, relmax
 
 pytestmark = pytest.mark.gpu
 
@@ -1270,6 +1270,9 @@ def _check_golden_rows(g, out1, out4, rows, what):
     assert_parity(std4, g["std"][:, 0], RTOL, f"std, fused launch ({what})")
     assert_parity(out4["Jvar"][rows], g["Jvar"][:, 0, :], RTOL, f"Jvar ({what})")
     assert_parity(out4["dvar"][:, rows], g["dvar"], RTOL, f"dvar ({what})")
+    print(f"{what}: mean {relmax(out1['mean'][rows], g['mean']):.1e}, std {relmax(std1, g['std'][:, 0]):.1e} / {relmax(std4, g['std'][:, 0]):.1e}, "
+          f"J {relmax(out1['J'][rows], g['J']):.1e}, Jvar {relmax(out4['Jvar'][rows], g['Jvar'][:, 0, :]):.1e}, "
+          f"dvar {relmax(out4['dvar'][:, rows], g['dvar']):.1e} (max-norm relative, vs the reference's vectors)")
 
 
 def test_headline_launch_shape_against_reference_vectors():
