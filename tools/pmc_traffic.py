@@ -1,5 +1,5 @@
 """Turn the PMC passes of tools/gpu_pmc.sh (run on the GPU box, merged back under gpurun_out/) into the record bench.py
-quotes as `roofline.traffic`: HBM-side bytes per launch of the dominant kernel.
+quotes as `roofline.traffic`: HBM-side bytes of the dominant kernel per prediction call (all its launches of one step).
 
     python tools/pmc_traffic.py gpurun_out/<tag> j 8192 500000 [commit]   # key (j | jvar | svgp), n_source, queries per launch,
                                                                           # commit the GPU run was made from (default: HEAD)
@@ -28,7 +28,9 @@ def counters(d, kernel_substr):
             c = row["Counter_Name"]
             acc[c] = acc.get(c, 0.0) + float(row["Counter_Value"])
             cnt[c] = cnt.get(c, 0) + 1
-    return {c: acc[c] / cnt[c] for c in acc}          # per dispatch
+    # the passes run ONE step (bench.py --steps 1 --warmup 0): the sum over the dispatches of that step — k_var goes out as several
+    # launches of 16 rounds since round 3 — is the figure per prediction call ("per launch" of the hot path)
+    return acc
 
 
 def main():
