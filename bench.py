@@ -299,6 +299,11 @@ def timed_steps(torch, dist, h, step, args, dev, use_dist, steps=None, warmup=No
     return elapsed, float(np.mean(var_ms)), float(np.mean(mj_ms))
 
 
+# k_var goes out as ceil(rounds / 16) launches per prediction call (csrc/gpt_predict.hip launch_var_t); the library's hipEvents
+# bracket all of them, and achieved / traffic are per call as well
+KERNEL_MS_IS = "all k_var launches of one step (rounds of 256 column blocks go out 16 per launch) + k_var_combine + k_var_finalize"
+
+
 def pmc_traffic(key, n_source, queries):
     """HBM-side traffic of the dominant kernel comes from a SEPARATE rocprofv3 --pmc run (profiles/pmc_traffic.json,
     written by tools/pmc_traffic.py with the workload and commit it was measured on); it is quoted only when this run's
@@ -353,7 +358,7 @@ def measure_exact(ctx, args, N, M, jvar, steps, warmup, c=0.1, noise=1e-4):
             "roofline": {"bound": "mfma", "kernel": "k_var (variance / Jacobian-variance triangular MFMA GEMM)",
                          "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel_ms": kern_ms, "mean_jac_kernel_ms": mj_ms}}
+                         "kernel_ms": kern_ms, "mean_jac_kernel_ms": mj_ms, "kernel_ms_is": KERNEL_MS_IS}}
 
 
 def measure_config1(_lib, steps=5):
@@ -539,7 +544,7 @@ def measure_svgp(ctx, args, Z, M, steps, warmup, h=None, bcast=None):
             "roofline": {"bound": "mfma", "kernel": "k_var<float> (stacked per-task triangular MFMA GEMM, v_mfma_f32_16x16x4_f32)",
                          "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel_ms": kern_ms, "mean_jac_kernel_ms": mj_ms}}
+                         "kernel_ms": kern_ms, "mean_jac_kernel_ms": mj_ms, "kernel_ms_is": KERNEL_MS_IS}}
 
 
 def run_svgp(args):
