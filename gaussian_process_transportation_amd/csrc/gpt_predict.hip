@@ -278,7 +278,8 @@ void launch_mean_jac(hipStream_t s, const KernelParams& p, const void* Xs, const
 // half the columns of the fused layout at exactly those two dimensions.
 // ------------------------------------------------------------------------------------------
 // Timing-only ablation builds (results are wrong unless 0): -DGPT_ABL=1 no per-chunk barrier, 2 no A-operand
-// loads, 3 diagonal tile skipped, 4 no B fill (LDS image left as is), 5 no MFMAs.  tools/gpu_ablate.sh,
+// loads, 3 diagonal tile skipped, 4 no B fill (LDS image left as is), 5 no MFMAs, 6 every wave 72 steps in the diagonal
+// tile of a reload sweep (the work of a SIMD's pair split evenly).  tools/gpu_ablate.sh,
 // profiles/r01_final_ablation.txt.
 #ifndef GPT_ABL
 #define GPT_ABL 0
@@ -577,7 +578,7 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
                 // lock-step, so the waves with g and 7 - g that share a SIMD add up to the same work on every SIMD: the tile
                 // costs 0.56 of a full one instead of the 0.75 it costs inside the lock-step pipeline.
                 const int kd0 = ib * WT_K4;                              // first k-step of the diagonal tile
-                const int limit = 16 * (g + 1);                          // multiple of 16
+                const int limit = (GPT_ABL == 6) ? 72 : 16 * (g + 1);    // multiple of 16 (ablation 6: every wave the average, 72: what an even split inside a SIMD would cost)
                 const avec* ap = wuni + (S_ib + kd0) * A_STEP;
                 const v4* bp = buni + (size_t)kd0 * 64;
                 auto ldA = [&](AF& a, const int k) {
