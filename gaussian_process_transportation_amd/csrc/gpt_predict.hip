@@ -811,8 +811,9 @@ static void var_kernel_setup() {
 
 // rounds of whole column blocks per launch of k_var (0: all in one launch); see launch_var_t
 static int var_rounds_per_launch() {
-    static const int v = [] { const char* e = getenv("GPT_VAR_ROUNDS_PER_LAUNCH"); return e ? atoi(e) : 16; }();
-    return v;
+    const char* e = getenv("GPT_VAR_ROUNDS_PER_LAUNCH");          // read per call: tests compare settings in one process
+    const int v = e ? atoi(e) : 16;
+    return v < 0 ? 0 : v;
 }
 
 template <typename T>
@@ -834,7 +835,8 @@ static void launch_var_t(hipStream_t s, const KernelParams& p, const VarWorkspac
     // run time (269.9-270.5 k/s in one launch, 270.9-271.3 k/s at 8-16), HBM-side bytes 4.99 -> 1.40 TB per 500k queries,
     // L2 hit rate 54 -> 86 % (profiles/r03_kvar_round_drift.txt).
     const int64_t rounds = pl_all.nfull / pl_all.P;
-    const int64_t rpl = var_rounds_per_launch() > 0 ? var_rounds_per_launch() : (rounds > 0 ? rounds : 1);
+    const int rpl_set = var_rounds_per_launch();
+    const int64_t rpl = rpl_set > 0 ? rpl_set : (rounds > 0 ? rounds : 1);
     for (int64_t r0 = 0; r0 == 0 || r0 < rounds; r0 += rpl) {
     VarPlanDev pl = pl_all;
     pl.rnd_begin = r0;

@@ -974,6 +974,30 @@ def test_small_batches_use_cut_sweeps_and_agree_with_large_batches(N, order, mon
     h.close()
 
 
+def test_rounds_dealt_to_several_launches_change_nothing(monkeypatch):
+    """k_var's rounds of whole column blocks go out 16 per launch (the workgroups re-align at every kernel boundary,
+    gpt_predict.hip launch_var_t).  A launch boundary must not change a bit: one launch for everything, one launch per
+    round and an uneven split (3 + 1 rounds, the item list with the last) against the default, for the 1-column, the
+    3-column and the fused 4-column kernels."""
+    from gaussian_process_transportation_amd import _lib
+    from oracle import gp_oracle as orc
+    X, Y, Xq = orc.synthetic_problem(1100, 70_000)           # 1094 column blocks: 4 rounds of 256 + a tail of 70
+    h = _lib.Handle(0)
+    h.fit(X, Y, np.array([0.1, 0.12, 0.09]), 0.1, 1e-4, 1e-10)
+    monkeypatch.delenv("GPT_VAR_ROUNDS_PER_LAUNCH", raising=False)
+    ref = h.predict_all(Xq, var=True, Jvar=True, dvar=True)
+    ref1 = h.predict_all(Xq, var=True)
+    ref3 = h.predict_all(Xq, Jvar=True)
+    for setting in ("0", "1", "3"):
+        monkeypatch.setenv("GPT_VAR_ROUNDS_PER_LAUNCH", setting)
+        out = h.predict_all(Xq, var=True, Jvar=True, dvar=True)
+        for k in ("var", "Jvar", "dvar"):
+            assert np.array_equal(out[k], ref[k]), f"{k}, {setting} rounds per launch"
+        assert np.array_equal(h.predict_all(Xq, var=True)["var"], ref1["var"])
+        assert np.array_equal(h.predict_all(Xq, Jvar=True)["Jvar"], ref3["Jvar"])
+    h.close()
+
+
 def test_non_finite_inputs_raise_like_sklearn():
     """sklearn's check_array refuses NaN / inf in X at fit and predict time (ValueError); Y rows with NaN are the
     reference's own filter (gaussian_process.py:33-35) and stay legal."""
