@@ -86,6 +86,7 @@ void launch_dot(hipStream_t s, const double* a, const double* b, int64_t n, doub
 // the caller's stream.
 struct FitAux {
     bool tried = false, ok = false;
+    int chain_eighths = 0;         // CUs of stream `sa` in eighths of the chip (the split the streams were made for)
     hipStream_t sa = nullptr, sb = nullptr;
     hipEvent_t e_fork = nullptr, e_a = nullptr, e_b = nullptr;
 };

@@ -995,14 +995,19 @@ void fit_aux_release(FitAux& aux) {
 // driver's numbering, dealt round-robin over the XCDs, so both halves span all 8 XCDs.  tools/probes/cumask_probe.hip: a
 // launch chain on one mask and a bulk kernel on the other run side by side without delaying each other, which two plain
 // streams do not (a short kernel queues behind the bulk kernel's grid).
-static bool fit_aux_init(FitAux& aux) {
-    if (aux.tried) return aux.ok;
+// `eighths`: CUs of the factorisation's second half in eighths of the chip — 3 (96 of 256) above NP = 6144, 4 up to it
+// (fit at N = 5000 / 6000: 3.76-3.89 / 5.14-5.29 ms with 96 CUs, 3.67 / 5.02 with 128; N = 7000 and 8192: 96 is best of 64 .. 160;
+// gpurun sessions r3cus, r3cus2).  A handle that changes size class gets new streams.
+static bool fit_aux_init(FitAux& aux, int eighths) {
+    if (aux.tried && (!aux.ok || aux.chain_eighths == eighths)) return aux.ok;
+    if (aux.tried) fit_aux_release(aux);
     aux.tried = true;
+    aux.chain_eighths = eighths;
     if (const char* env = getenv("GPT_FIT_OVERLAP")) { if (atoi(env) == 0) return false; }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, current_device()) != hipSuccess) return false;
     const int ncu = prop.multiProcessorCount;
-    int split = ncu * 3 / 8;                             // CUs of the factorisation's second half (96 of 256: measured best of 64..160)
+    int split = ncu * eighths / 8;
     if (const char* e = getenv("GPT_FIT_CHAIN_CUS")) split = atoi(e);
     if (split < 16 || split > ncu - 16) return false;
     const int words = (ncu + 31) / 32;
@@ -1033,7 +1038,7 @@ void launch_factor_inverse(hipStream_t s, double* K, double* W, int NP, int* inf
     const int nb = NP / NB;
     const int gw = potrf_group(NP) * potrf_outer_blocks();
     int hb = nb / 2 / gw * gw;                                      // split block column, group-aligned
-    const bool overlap = NP > 4096 && NP <= 12288 && hb >= gw && aux && fit_aux_init(*aux);
+    const bool overlap = NP > 4096 && NP <= 12288 && hb >= gw && aux && fit_aux_init(*aux, NP <= 6144 ? 4 : 3);
     if (!overlap) {
         potrf_groups(s, K, W, NP, info, 0, nb);
         potrf_finish(s, K, W, NP, 0, nb);
