@@ -1037,8 +1037,11 @@ size_t factor_scratch_doubles(int NP) { return (size_t)NP * NP / 4 + (size_t)NP 
 void launch_factor_inverse(hipStream_t s, double* K, double* W, int NP, int* info, double* scratch, FitAux* aux, hipEvent_t ev_factored) {
     const int nb = NP / NB;
     const int gw = potrf_group(NP) * potrf_outer_blocks();
-    int hb = nb / 2 / gw * gw;                                      // split block column, group-aligned
-    const bool overlap = NP > 4096 && NP <= 12288 && hb >= gw && aux && fit_aux_init(*aux, NP <= 6144 ? 4 : 3);
+    int hb = nb / 2 / gw * gw;                                      // split block column, group-aligned.  NOT tunable as is: the scratch
+                                                                    // layout below (T21 in NP^2/4, half-size inverses in NP^2/16) assumes h <= NP/2 <= r + gw*NB
+    const size_t r_split = (size_t)NP - (size_t)hb * NB;            // rows of the second half
+    const bool fits = r_split * r_split / 4 <= (size_t)NP * NP / 16 + 4096;      // its inverse's scratch (a split off the half, e.g. GPT_POTRF_GROUP=4: serial form)
+    const bool overlap = NP > 4096 && NP <= 12288 && hb >= gw && fits && aux && fit_aux_init(*aux, NP <= 6144 ? 4 : 3);
     if (!overlap) {
         potrf_groups(s, K, W, NP, info, 0, nb);
         potrf_finish(s, K, W, NP, 0, nb);
