@@ -563,37 +563,6 @@ struct TilePos { int b, ti, tj; bool ok; };
 __device__ __forceinline__ TilePos gemm_decode(const GemmArgs& g, int TM, int TN, int G, int fold_tm, const int vid) {
     TilePos t{0, 0, 0, false};
     const int xcd = vid & 7, sidx = vid >> 3;
-    if (fold_tm < 0) {
-        // Square lower-triangular tile set (T x T, tj <= ti) in BANDS of 8 consecutive tile rows: band beta goes whole to one
-        // XCD (bands dealt boustrophedon, 0..7, 7..0, ..., so every XCD gets long and short ones; longest first), and the XCD
-        // walks a band column by column, its 8 rows together.  The ~128 tiles an XCD runs at a time are then 8 rows x 16
-        // columns of ONE band: 8 row panels that stay in its L2 for the whole band and a sliding window of 16 column panels,
-        // each read once per band — where the folded order above has every row of the XCD stream its own diagonal of column
-        // panels (36 % of the panel requests of a rank-256 update missed L2: profiles/r03_fit_gemm_pmc.txt).
-        const int T = -fold_tm;
-        const int nbands = (T + 7) / 8;
-        int rem = sidx, r0 = 0, nr = 0;
-        bool found = false;
-        for (int k = (nbands - 1) / 8; k >= 0; --k) {
-            const int beta = 8 * k + ((k & 1) ? 7 - xcd : xcd);
-            if (beta >= nbands) continue;
-            r0 = 8 * beta;
-            nr = T - r0 < 8 ? T - r0 : 8;
-            const int cnt = r0 * nr + nr * (nr + 1) / 2;
-            if (rem < cnt) { found = true; break; }
-            rem -= cnt;
-        }
-        if (!found) return t;
-        if (rem < r0 * nr) { t.tj = rem / nr; t.ti = r0 + rem % nr; }
-        else {
-            rem -= r0 * nr;
-            int c = 0;
-            while (rem >= nr - c) { rem -= nr - c; ++c; }
-            t.tj = r0 + c; t.ti = r0 + c + rem;
-        }
-        t.ok = true;
-        return t;
-    }
     int gi;
     if (g.a_lower)        { gi = G - 1 - sidx / TN; t.tj = sidx % TN; }     // long rows first
     else if (g.k_from_ij) { gi = sidx / TN;         t.tj = sidx % TN; }     // short offsets first
@@ -786,25 +755,6 @@ static GemmGrid gemm_grid(const GemmArgs& g, int TS) {
     const int Mmax = g.nbatch == 1 ? g.M_last : (g.M > g.M_last ? g.M : g.M_last);
     q.TM = (Mmax + TS - 1) / TS; q.TN = (g.N + TS - 1) / TS;
     static const bool nofold = [] { const char* e = getenv("GPT_GEMM_NOFOLD"); return e && atoi(e) != 0; }();
-    static const int band_min = [] { const char* e = getenv("GPT_GEMM_BAND_MIN"); return e ? atoi(e) : 1 << 30; }();   // diagnostic (unbalanced between XCDs unless T is a multiple of 128): off
-    if (g.lower_only && g.nbatch == 1 && q.TM == q.TN && !g.k_from_ij && q.TM >= band_min) {
-        const int T = q.TM, nbands = (T + 7) / 8;
-        int most = 0;
-        for (int x = 0; x < 8; ++x) {
-            int tot = 0;
-            for (int k = 0; k <= (nbands - 1) / 8; ++k) {
-                const int beta = 8 * k + ((k & 1) ? 7 - x : x);
-                if (beta >= nbands) continue;
-                const int r0 = 8 * beta, nr = T - r0 < 8 ? T - r0 : 8;
-                tot += r0 * nr + nr * (nr + 1) / 2;
-            }
-            if (tot > most) most = tot;
-        }
-        q.fold_tm = -T;
-        q.G = 0;
-        q.nvid = 8 * most;
-        return q;
-    }
     if (!nofold && g.lower_only && g.nbatch == 1 && q.TM == q.TN && q.TM > 1) { q.fold_tm = q.TM; q.TM = (q.fold_tm + 1) / 2; q.TN = q.fold_tm + 1; }
     q.G = (g.nbatch * q.TM + 7) / 8;            // tile rows (over all batch entries) per XCD
     q.nvid = 8 * q.G * q.TN;
