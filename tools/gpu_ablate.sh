@@ -5,7 +5,7 @@ set -u
 OUT=gpurun_out/${1:-ablate}; mkdir -p "$OUT"
 B=$PWD/gaussian_process_transportation_amd/csrc/build
 make -C gaussian_process_transportation_amd/csrc ablate > "$OUT/build.log" 2>&1 || { echo "ablation build failed"; exit 1; }
-for v in 0 1 2 3 4 5; do
+for v in 0 1 2 3 4 5 6; do
   if [ $v -eq 0 ]; then LIB=$PWD/gaussian_process_transportation_amd/libgpt_hip.so; else LIB=$B/libgpt_abl$v.so; fi
   GPT_BENCH_ABLATE=1 GPT_HIP_LIB=$LIB timeout -k 10 200 python bench.py --steps 2 --warmup 1 --cpu-sample 0 > "$OUT/abl$v.log" 2>&1
   rc=$?
