@@ -515,14 +515,6 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) acc[r][t] = v4{0, 0, 0, 0};
-#ifdef GPT_MJ_PROBE
-            v4 mjacc = v4{0, 0, 0, 0};
-            const int mj_last = p.NP / 4 - 1;                                     // stand-in for the [source][16] image: rows of Xs, in bounds
-            auto mj_ld = [&](const int k4s) { const int kk = k4s < mj_last ? k4s : mj_last; return Xs[(size_t)(kk * 4 + lk) * XS + (lc & 3)]; };
-            T amj_cur = GEN ? mj_ld(K0 + (w >> 2)) : (T)0, amj_nxt = (T)0;
-            const bool mj_odd = (w >> 2) != 0;
-            const int mj_t = w & 3;
-#endif
             const int my_limit = ib * WT_K4 + 16 * (g + 1);     // first k4-step of the i-block with nothing left for this group
             // Sources of the fills inside the loop, as loop-carried per-lane pointers (k-step K0 + VAR_CH + w first, then
             // VAR_SUB further each time): an address recomputed from the k-step lands in whatever registers are free —
@@ -561,15 +553,6 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
                         if (sn < VAR_CH) b_nxt = *reinterpret_cast<const v4*>(Bs(cur, sn));
                         if (GPT_ABL == 5) { El<T>::keep(a, b); return; }
                         El<T>::mfma16(acc, a, b);
-#ifdef GPT_MJ_PROBE
-                        if (GEN && NCOMP == 1 && (s & 1) == 0) {
-                            amj_nxt = mj_ld(k4 + 2 + (w >> 2));
-                            T x0 = mj_odd ? b_nxt[0] : b[0], x1 = mj_odd ? b_nxt[1] : b[1], x2 = mj_odd ? b_nxt[2] : b[2], x3 = mj_odd ? b_nxt[3] : b[3];
-                            const T bs = (mj_t == 0) ? x0 : ((mj_t == 1) ? x1 : ((mj_t == 2) ? x2 : x3));
-                            mjacc = El<T>::mfma(amj_cur, bs, mjacc);
-                            amj_cur = amj_nxt;
-                        }
-#endif
                     };
                     // The fill of the next chunk sits INSIDE the active / idle paths, not behind their join: vmcnt counts in
                     // issue order, and behind a join hipcc has to wait for vmcnt(0) — which also waits for the A fragments
@@ -659,11 +642,6 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
                     }
                 }
             }
-#ifdef GPT_MJ_PROBE
-            if (GEN && NCOMP == 1) {
-                for (int e = 0; e < 4; ++e) ssq[e & 3] += mjacc[e] * (T)1e-300;          // keep it alive (probe only)
-            }
-#endif
             if (vslot >= 0) {
                 // cut sweep: this part's 512 x 64 partial product goes to vslab, [vslot][wave][r*4+t][lane] (k_var_combine)
                 v4* dst = reinterpret_cast<v4*>(vslab) + ((size_t)vslot * 8 + w) * (16 * 64) + lane;
