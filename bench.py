@@ -404,10 +404,12 @@ def run_exact(args):
         X, Y = synthetic_sources(N, D)
         ls = np.array([0.1] * D)
         h.fit(X, Y, ls, 0.1, 1e-4, 1e-10)                  # first call: allocations + code load
-        t0 = time.perf_counter()
-        h.fit(X, Y, ls, 0.1, 1e-4, 1e-10)
-        fit_ms = (time.perf_counter() - t0) * 1e3
-        fit_timings = h.fit_timings()
+        for _ in range(3):                                 # fastest of three repeat fits (the second call is still 4 % slow:
+            t0 = time.perf_counter()                       # tools/fit_stream_probe.py 9.83-9.91 ms, then 9.45-9.55)
+            h.fit(X, Y, ls, 0.1, 1e-4, 1e-10)
+            ms = (time.perf_counter() - t0) * 1e3
+            if fit_ms is None or ms < fit_ms:
+                fit_ms, fit_timings = ms, h.fit_timings()
     bcast_ms, bcast_bytes = broadcast_fitted(torch, dist, h, rank, dev, use_dist)
 
     ctx = (torch, dist, h, rank, world, dev, use_dist)
