@@ -448,6 +448,13 @@ def run_exact(args):
             "fit_ms": fit_ms, "fit_phases_ms": fit_timings, "bcast_ms": bcast_ms, "bcast_bytes": bcast_bytes,
             "ranks_seen": ranks_seen,
         }
+        if fit_timings:
+            # factorisation + explicit inverse: N^3/3 flop each (sklearn/_gpr.py:346-364, gaussian_process.py:42-43)
+            fi_ms = fit_timings["cholesky"] + fit_timings["inverse"]
+            fi_tf = (2.0 * N ** 3 / 3.0) / (fi_ms * 1e-3) / 1e12
+            out["fit_roofline"] = {"bound": "mfma", "what": "Cholesky + triangular inverse, 2 N^3 / 3 flop, device events of the fastest repeat fit",
+                                   "kernel_ms": fi_ms, "achieved": fi_tf, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": fi_tf / PEAK_FP64_MFMA_TFLOPS}
         if use_dist and bcast_ms is not None:
             # "include broadcast time in cfg4's number" — `value` times the K steps only (a model is broadcast
             # once per fit, not per batch); value_incl_bcast charges the one broadcast to these K steps
