@@ -835,8 +835,13 @@ static void launch_var_t(hipStream_t s, const KernelParams& p, const VarWorkspac
     // run time (269.9-270.5 k/s in one launch, 270.9-271.3 k/s at 8-16), HBM-side bytes 4.99 -> 1.40 TB per 500k queries,
     // L2 hit rate 54 -> 86 % (profiles/r03_kvar_round_drift.txt).
     const int64_t rounds = pl_all.nfull / pl_all.P;
+    // (the setting is in rounds of the shape it was measured on — 136 tiles per block, N = 8192; a launch of a smaller model
+    // gets as many rounds as make the same number of tiles, so that the boundaries stay ~0.1 % of the run time)
     const int rpl_set = var_rounds_per_launch();
-    const int64_t rpl = rpl_set > 0 ? rpl_set : (rounds > 0 ? rounds : 1);
+    const int64_t tiles_per_round = (int64_t)pl_all.ntask * pl_all.tiles_per_task;
+    const int64_t rpl_scaled = tiles_per_round > 0 ? ((int64_t)rpl_set * 136 + tiles_per_round - 1) / tiles_per_round : rpl_set;
+    int64_t rpl = rpl_set > 0 ? (rpl_scaled > rpl_set ? rpl_scaled : rpl_set) : (rounds > 0 ? rounds : 1);
+    if (const char* e = getenv("GPT_VAR_ROUNDS_EXACT")) { if (atoi(e) > 0) rpl = atoi(e); }      // tests: this many, whatever the shape
     for (int64_t r0 = 0; r0 == 0 || r0 < rounds; r0 += rpl) {
     VarPlanDev pl = pl_all;
     pl.rnd_begin = r0;

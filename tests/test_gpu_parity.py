@@ -985,14 +985,15 @@ def test_rounds_dealt_to_several_launches_change_nothing(monkeypatch):
     h = _lib.Handle(0)
     h.fit(X, Y, np.array([0.1, 0.12, 0.09]), 0.1, 1e-4, 1e-10)
     monkeypatch.delenv("GPT_VAR_ROUNDS_PER_LAUNCH", raising=False)
-    ref = h.predict_all(Xq, var=True, Jvar=True, dvar=True)
+    monkeypatch.delenv("GPT_VAR_ROUNDS_EXACT", raising=False)
+    ref = h.predict_all(Xq, var=True, Jvar=True, dvar=True)          # default: 16 rounds of the N = 8192 shape = all 4 here
     ref1 = h.predict_all(Xq, var=True)
     ref3 = h.predict_all(Xq, Jvar=True)
-    for setting in ("0", "1", "3"):
-        monkeypatch.setenv("GPT_VAR_ROUNDS_PER_LAUNCH", setting)
+    for setting in ("1", "3", "2"):
+        monkeypatch.setenv("GPT_VAR_ROUNDS_EXACT", setting)
         out = h.predict_all(Xq, var=True, Jvar=True, dvar=True)
         for k in ("var", "Jvar", "dvar"):
-            assert np.array_equal(out[k], ref[k]), f"{k}, {setting} rounds per launch"
+            assert np.array_equal(out[k], ref[k]), f"{k}, exactly {setting} rounds per launch"
         assert np.array_equal(h.predict_all(Xq, var=True)["var"], ref1["var"])
         assert np.array_equal(h.predict_all(Xq, Jvar=True)["Jvar"], ref3["Jvar"])
     h.close()
