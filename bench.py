@@ -299,9 +299,10 @@ def timed_steps(torch, dist, h, step, args, dev, use_dist, steps=None, warmup=No
     return elapsed, float(np.mean(var_ms)), float(np.mean(mj_ms))
 
 
-# k_var goes out as ceil(rounds / 16) launches per prediction call (csrc/gpt_predict.hip launch_var_t); the library's hipEvents
+# k_var goes out as several launches per prediction call (csrc/gpt_predict.hip launch_var_t); the library's hipEvents
 # bracket all of them, and achieved / traffic are per call as well
-KERNEL_MS_IS = "all k_var launches of one step (rounds of 256 column blocks go out 16 per launch) + k_var_combine + k_var_finalize"
+KERNEL_MS_IS = ("all k_var launches of one step (the rounds of 256 column blocks go out 16 per launch at the N = 8192 shape, "
+                "proportionally more for smaller models) + k_var_combine + k_var_finalize")
 
 
 def pmc_traffic(key, n_source, queries):
