@@ -51,9 +51,11 @@ SIGNATURES = {
     "gpt_factor_alloc": (C.c_int, [_vp, _i64, C.c_int, C.c_int, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
     "gpt_factor_alloc_model": (C.c_int, [_vp, _i64, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
     "gpt_factor_commit": (C.c_int, [_vp]),
+    "gpt_factor_copy": (C.c_int, [_vp, _vp]),
     "gpt_model_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "gpt_debug_var_plan": (C.c_int, [_i64, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_i64), C.POINTER(C.c_int),
                                      C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "gpt_debug_fit_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
     "gpt_info": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_i64)]),
     "gpt_fit_timings": (C.c_int, [_vp, _dp, C.c_int]),
     "gpt_set_profiling": (C.c_int, [_vp, C.c_int]),
@@ -166,6 +168,19 @@ def debug_var_plan(n_columns, n_iblocks, n_tasks, n_workgroups, order=-1):
     return {"n_items": counts[0], "n_splits": counts[1], "n_slots": counts[2], "n_vslots": counts[3], "ncb": counts[4],
             "nfull": counts[5], "order": counts[7], "item_begin": item_begin, "items": items[:counts[0]],
             "fin": fin[:counts[6]], "splits": splits[:counts[1]]}
+
+
+FIT_OP_KINDS = ("LEAF_FACTOR", "LEAF_INVERSE", "L21", "COPY_L21", "SYRK", "FORK", "T21", "JOIN", "W21", "FACTORED")
+
+
+def debug_fit_plan(n_padded, leaf=-1, rec_min=-1, fork_min=-1):
+    """The plan of the recursive factor + inverse (csrc/gpt_fit_plan.h) for a padded size; host code, no GPU."""
+    lib = load()
+    counts = (_i64 * 5)()
+    check(lib.gpt_debug_fit_plan(n_padded, leaf, rec_min, fork_min, counts, None))
+    ops = np.zeros((max(counts[0], 1), 10), dtype=np.int64)
+    check(lib.gpt_debug_fit_plan(n_padded, leaf, rec_min, fork_min, counts, ops.ctypes.data_as(C.POINTER(_i64))))
+    return {"arena": counts[1], "recursive": bool(counts[2]), "depth": counts[3], "allocated": counts[4], "ops": ops[:counts[0]]}
 
 
 class Handle:
@@ -359,3 +374,7 @@ class Handle:
 
     def factor_commit(self):
         check(self.lib.gpt_factor_commit(self._h), "gpt_factor_commit")
+
+    def factor_copy_from(self, src: "Handle"):
+        """This handle becomes a replica of `src`'s fitted model (same process, any device): gpt_factor_copy."""
+        check(self.lib.gpt_factor_copy(self._h, src._h), "gpt_factor_copy")

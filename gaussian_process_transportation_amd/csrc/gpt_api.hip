@@ -3,6 +3,7 @@
 // on one HIP stream and maps failures to error codes.
 #include "gpt_common.h"
 #include "gpt_plan.h"
+#include "gpt_fit_plan.h"
 #include "../../include/gpt_hip.h"
 
 #include <cmath>
@@ -159,7 +160,8 @@ struct gpt_handle {
     // fit workspace (fp64)
     double *dK = nullptr, *dW = nullptr, *dY4 = nullptr, *dT4 = nullptr, *dTa = nullptr, *dXs64 = nullptr, *dA64 = nullptr, *dscal = nullptr;
     double* dXraw = nullptr;       // the raw (N, D) sources as uploaded; scaled on the device for every new set of length-scales
-    double* dScr = nullptr;        // scratch of the triangular inverse (NP^2/4) and of alpha's backward pass
+    double* dScr = nullptr;        // arena of the factor + inverse (gpt_fit_plan.h) and scratch of alpha's backward pass
+    size_t scr_doubles = 0;        // its capacity
     int* dinfo = nullptr;
     int64_t ws_np = 0;
     int ws_npass = 0;
@@ -215,6 +217,7 @@ void free_workspace(gpt_handle* h) {
     if (h->dinfo) (void)hipFree(h->dinfo);
     h->dinfo = nullptr;
     h->ws_np = 0; h->ws_npass = 0; h->have_L = h->have_W = false;
+    h->scr_doubles = 0;
 }
 
 int ensure_blob(gpt_handle* h, const Layout& l) {
@@ -231,8 +234,22 @@ int ensure_blob(gpt_handle* h, const Layout& l) {
     return GPT_OK;
 }
 
+// the factor + inverse arena: sized by the plan THIS fit will run (the plan depends on diagnostic environment knobs, which a
+// process may change between two fits of one handle)
+int ensure_scratch(gpt_handle* h, int64_t NP) {
+    const size_t a = factor_scratch_doubles((int)NP), b = (size_t)(NP / 512) * NP * 4;
+    const size_t need = a > b ? a : b;
+    if (h->dScr && h->scr_doubles >= need) return GPT_OK;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->dScr) (void)hipFree(h->dScr);
+    h->dScr = nullptr; h->scr_doubles = 0;
+    HIPCHK(hipMalloc(&h->dScr, need * sizeof(double)));
+    h->scr_doubles = need;
+    return GPT_OK;
+}
+
 int ensure_workspace(gpt_handle* h, int64_t NP, int npass) {
-    if (h->ws_np == NP && h->ws_npass >= npass && h->dK) return GPT_OK;
+    if (h->ws_np == NP && h->ws_npass >= npass && h->dK) return ensure_scratch(h, NP);
     HIPCHK(hipStreamSynchronize(h->stream));
     free_workspace(h);
     HIPCHK(hipMalloc(&h->dK, (size_t)NP * NP * sizeof(double)));
@@ -245,10 +262,7 @@ int ensure_workspace(gpt_handle* h, int64_t NP, int npass) {
     HIPCHK(hipMalloc(&h->dXraw, (size_t)NP * MAX_D * sizeof(double)));
     HIPCHK(hipMalloc(&h->dscal, 16 * sizeof(double)));
     HIPCHK(hipMalloc(&h->dinfo, sizeof(int)));
-    {
-        const size_t a = factor_scratch_doubles((int)NP), b = (size_t)(NP / 512) * NP * 4;
-        HIPCHK(hipMalloc(&h->dScr, (a > b ? a : b) * sizeof(double)));
-    }
+    if (int rc = ensure_scratch(h, NP)) return rc;
     h->ws_np = NP; h->ws_npass = npass;
     return GPT_OK;
 }
@@ -943,6 +957,40 @@ int gpt_factor_commit(gpt_handle* h) {
     return GPT_OK;
 }
 
+int gpt_factor_copy(gpt_handle* dst, gpt_handle* src) {
+    if (!dst || !src) return fail(GPT_E_ARG, "gpt_factor_copy: NULL handle");
+    if (dst == src) return fail(GPT_E_ARG, "gpt_factor_copy: source and destination are the same handle");
+    if (!src->committed || !src->blob) return fail(GPT_E_STATE, "gpt_factor_copy: source handle holds no fitted model");
+    // the source's kernels (fit, pack) have to be done before another device reads the blob
+    if (int rc = set_device(src)) return rc;
+    HIPCHK(hipStreamSynchronize(src->stream));
+    double hdr[HDR_DOUBLES];
+    HIPCHK(hipMemcpy(hdr, src->blob, sizeof hdr, hipMemcpyDeviceToHost));
+    if (hdr[0] != MAGIC) return fail(GPT_E_STATE, "gpt_factor_copy: source blob has no model header");
+    const Layout l = src->lay;
+    if (int rc = set_device(dst)) return rc;
+    dst->committed = false;
+    dst->have_L = dst->have_W = false;
+    dst->objective_ready = false;
+    if (int rc = ensure_blob(dst, l)) return rc;
+    if (dst->device == src->device) {
+        HIPCHK(hipMemcpyAsync(dst->blob, src->blob, l.total, hipMemcpyDeviceToDevice, dst->stream));
+    } else {
+        // device to device over xGMI (peer access is enabled on demand; without it the runtime stages through the host)
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, dst->device, src->device) == hipSuccess && can) {
+            hipError_t e = hipDeviceEnablePeerAccess(src->device, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+            else (void)hipGetLastError();
+        }
+        HIPCHK(hipMemcpyPeerAsync(dst->blob, dst->device, src->blob, src->device, l.total, dst->stream));
+    }
+    HIPCHK(hipStreamSynchronize(dst->stream));
+    fill_params(dst, hdr);
+    dst->committed = true;
+    return GPT_OK;
+}
+
 int gpt_info(gpt_handle* h, int64_t* N, int* D, int* O, int64_t* N_padded) {
     if (!h) return fail(GPT_E_ARG, "gpt_info: NULL handle");
     if (!h->committed) return fail(GPT_E_STATE, "gpt_info: model is not fitted");
@@ -1002,6 +1050,21 @@ int gpt_debug_var_plan(int64_t n_columns, int n_iblocks, int n_tasks, int n_work
     if (items && !pl.items.empty()) memcpy(items, pl.items.data(), pl.items.size() * sizeof(VarItem));
     if (fin && !pl.fin.empty()) memcpy(fin, pl.fin.data(), pl.fin.size() * sizeof(int));
     if (splits && !pl.splits.empty()) memcpy(splits, pl.splits.data(), pl.splits.size() * sizeof(VarSplit));
+    return GPT_OK;
+}
+
+int gpt_debug_fit_plan(int n_padded, int leaf, int rec_min, int fork_min, int64_t* counts, int64_t* ops) {
+    if (n_padded < 64 || n_padded % 64 != 0 || !counts) return fail(GPT_E_ARG, "gpt_debug_fit_plan: bad argument");
+    const FitPlan pl = fit_plan(n_padded, leaf, rec_min, fork_min);
+    counts[0] = (int64_t)pl.ops.size(); counts[1] = (int64_t)pl.arena; counts[2] = pl.recursive ? 1 : 0; counts[3] = pl.max_depth;
+    counts[4] = (int64_t)factor_scratch_doubles_of(n_padded);
+    if (ops)
+        for (size_t i = 0; i < pl.ops.size(); ++i) {
+            const FitOp& o = pl.ops[i];
+            int64_t* r = ops + 10 * i;
+            r[0] = o.kind; r[1] = o.side; r[2] = o.depth; r[3] = o.off; r[4] = o.n1; r[5] = o.n2;
+            r[6] = (int64_t)o.r0; r[7] = (int64_t)o.r0_size; r[8] = (int64_t)o.r1; r[9] = (int64_t)o.r1_size;
+        }
     return GPT_OK;
 }
 

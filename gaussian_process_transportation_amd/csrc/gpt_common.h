@@ -89,9 +89,13 @@ struct FitAux {
     int chain_eighths = 0;         // CUs of stream `sa` in eighths of the chip (the split the streams were made for)
     hipStream_t sa = nullptr, sb = nullptr;
     hipEvent_t e_fork = nullptr, e_a = nullptr, e_b = nullptr;
+    // recursive form (gpt_fit_plan.h): one side stream on most of the CUs for the T21 products, an event pair per depth
+    bool side_tried = false, side_ok = false;
+    hipStream_t side = nullptr;
+    hipEvent_t side_fork[16] = {}, side_join[16] = {};
 };
 void fit_aux_release(FitAux& aux);
-size_t factor_scratch_doubles(int NP);
+size_t factor_scratch_doubles(int NP);        // gpt_fit_plan.h
 // L = chol(K) in place (lower), W = L^-1; scratch >= factor_scratch_doubles(NP); ev_factored (may be null) is recorded
 // in `s` when L is complete
 void launch_factor_inverse(hipStream_t s, double* K, double* W, int NP, int* info, double* scratch, FitAux* aux, hipEvent_t ev_factored);

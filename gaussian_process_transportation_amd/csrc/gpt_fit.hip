@@ -8,6 +8,7 @@
 // kept as its triangular factor W = L^-1 so that k^T K^-1 k = |W k|^2).
 #include "gpt_common.h"
 #include "gpt_exp.h"
+#include "gpt_fit_plan.h"
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
@@ -525,6 +526,7 @@ struct GemmArgs {
     int lower_only;          // skip tiles strictly above the block diagonal (SYRK)
     int a_lower;             // A lower triangular: k < i0 + TS
     int b_lower;             // B lower triangular (BT=false): k >= j0
+    int bt_lower;            // B lower triangular, used transposed (BT=true, B stored [n][k]): k < j0 + TS
     int k_from_ij;           // both operands vanish for k < max(i0, j0) (W^T W with W lower triangular)
     int stagger;             // diagnostic: < 0 = rows of a folded triangle dealt round-robin over the XCDs (the round-2 order)
 };
@@ -566,6 +568,7 @@ __device__ __forceinline__ TilePos gemm_decode(const GemmArgs& g, int TM, int TN
     int gi;
     if (g.a_lower)        { gi = G - 1 - sidx / TN; t.tj = sidx % TN; }     // long rows first
     else if (g.k_from_ij) { gi = sidx / TN;         t.tj = sidx % TN; }     // short offsets first
+    else if (g.bt_lower)  { t.tj = TN - 1 - sidx / G; gi = sidx % G; }      // column by column, long columns first
     else                  { t.tj = sidx / G;        gi = sidx % G; }        // column by column
     int R = 8 * gi + ((gi & 1) ? 7 - xcd : xcd);
     if (fold_tm && g.stagger >= 0 && !g.k_from_ij) {
@@ -617,6 +620,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int TM, int TN, int
     int kbeg = 0, kend = K;
     if (g.a_lower) kend = min(K, i0 + TS);
     if (g.b_lower) kbeg = j0;
+    if (g.bt_lower) kend = min(K, j0 + TS);
     if (g.k_from_ij) kbeg = i0 > j0 ? i0 : j0;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int wr = w >> 1, wc = w & 1;
@@ -845,8 +849,9 @@ static int potrf_group(int NP) {
 }
 
 // Trailing update of the Cholesky: A[row0.., row0..row0+ncols) -= P P^T on the block lower triangle, P = A[row0.., kcol0..kcol0+kw)
-static void syrk_update(hipStream_t s, double* K, int NP, int row0, int ncols, int kcol0, int kw) {
-    const int rem = NP - row0;
+// (rows [row0, row_end): the whole matrix behind row0, or the diagonal block a leaf of the recursive form is confined to)
+static void syrk_update(hipStream_t s, double* K, int NP, int row0, int ncols, int kcol0, int kw, int row_end = -1) {
+    const int rem = (row_end < 0 ? NP : row_end) - row0;
     if (rem <= 0 || kw <= 0) return;
     GemmArgs c{};
     c.A = K + (size_t)row0 * NP + kcol0; c.lda = NP;
@@ -859,8 +864,9 @@ static void syrk_update(hipStream_t s, double* K, int NP, int row0, int ncols, i
     launch_gemm<true>(s, c);
 }
 
-static void potrf_groups(hipStream_t s, double* K, double* W, int NP, int* info, int blk_begin, int blk_end) {
-    const int nb = NP / NB;
+// row_blk_end: block rows [.., row_blk_end) take part (NP / NB for the whole matrix; blk_end for a leaf of the recursive form)
+static void potrf_groups(hipStream_t s, double* K, double* W, int NP, int* info, int blk_begin, int blk_end, int row_blk_end, int grp_override = 0) {
+    const int nb = row_blk_end;
     const int ob = potrf_outer_blocks();
     constexpr size_t step_lds = (size_t)(2 * NB * PS) * sizeof(double);
     constexpr size_t fin_lds = (size_t)(2 * NB * DS) * sizeof(double);
@@ -875,8 +881,8 @@ static void potrf_groups(hipStream_t s, double* K, double* W, int NP, int* info,
     // (42 TFLOP/s against 50-55 at rank 256-512), happens grp times less often.
     // (measured: groups of 2 take 3 % off the Cholesky at N = 8192 and add 3-5 % at N <= 2500, where the extra thin GEMM
     // on the chain costs more than the trailing matrix's traffic; tools/gpu_fit_ab.sh with GPT_POTRF_GROUP)
-    const int grp = potrf_group(NP);
-    auto syrk = [&](int row0, int ncols, int kcol0, int kw) { syrk_update(s, K, NP, row0, ncols, kcol0, kw); };
+    const int grp = grp_override > 0 ? grp_override : potrf_group(NP);
+    auto syrk = [&](int row0, int ncols, int kcol0, int kw) { syrk_update(s, K, NP, row0, ncols, kcol0, kw, nb * NB); };
     const int gw = grp * ob;                                        // blocks per group
     for (int g0 = blk_begin; g0 < blk_end; g0 += gw) {
         const int gend = g0 + gw < nb ? g0 + gw : nb;
@@ -886,7 +892,7 @@ static void potrf_groups(hipStream_t s, double* K, double* W, int NP, int* info,
             for (int kb = p0; kb < pend; ++kb)
                 hipLaunchKernelGGL(k_potrf_step, dim3(nb - kb), dim3(256), step_lds, s, K, W, NP, kb, p0, info GPT_TRACE_NULL);
         }
-        syrk(gend * NB, NP - gend * NB, g0 * NB, (gend - g0) * NB);                  // everything behind the group
+        syrk(gend * NB, nb * NB - gend * NB, g0 * NB, (gend - g0) * NB);             // everything behind the group
     }
 }
 
@@ -939,6 +945,40 @@ void fit_aux_release(FitAux& aux) {
     if (aux.sb) (void)hipStreamDestroy(aux.sb);
     aux.sa = aux.sb = nullptr;
     aux.tried = aux.ok = false;
+    for (auto& e : aux.side_fork) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+    for (auto& e : aux.side_join) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+    if (aux.side) (void)hipStreamDestroy(aux.side);
+    aux.side = nullptr;
+    aux.side_tried = aux.side_ok = false;
+}
+
+// The side stream of the recursive form: T21 = L21 W11 of a level is needed only by that level's W21, after the whole second
+// half has been factored — it runs beside the second half's launch chains on a stream confined to `eighths`/8 of the CUs (bit i
+// of the mask = CU i, dealt round-robin over the XCDs: every XCD keeps 4 CUs free at 7/8), so that a k_potrf_step of the main
+// stream never queues behind a side GEMM's grid (tools/probes/cumask_probe.hip: two plain streams do make it queue).
+static bool fit_side_init(FitAux& aux) {
+    if (aux.side_tried) return aux.side_ok;
+    aux.side_tried = true;
+    if (fit_env_int("GPT_FIT_OVERLAP", 1) == 0) return false;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, current_device()) != hipSuccess) return false;
+    const int ncu = prop.multiProcessorCount;
+    const int eighths = fit_env_int("GPT_FIT_SIDE_EIGHTHS", 7);
+    const int n_side = ncu * eighths / 8;
+    if (eighths >= 8) {
+        if (hipStreamCreateWithFlags(&aux.side, hipStreamNonBlocking) != hipSuccess) { aux.side = nullptr; (void)hipGetLastError(); return false; }
+    } else {
+        if (n_side < 16) return false;
+        const int words = (ncu + 31) / 32;
+        std::vector<uint32_t> m(words, 0);
+        for (int i = 0; i < n_side; ++i) m[i / 32] |= 1u << (i % 32);
+        if (hipExtStreamCreateWithCUMask(&aux.side, words, m.data()) != hipSuccess) { aux.side = nullptr; (void)hipGetLastError(); return false; }
+    }
+    bool ok = true;
+    for (auto& e : aux.side_fork) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+    for (auto& e : aux.side_join) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+    aux.side_ok = ok;
+    return ok;
 }
 
 // Two CU-masked streams (hipExtStreamCreateWithCUMask): bits [0, split) and the rest — bit i of the mask is CU i in the
@@ -974,7 +1014,90 @@ static bool fit_aux_init(FitAux& aux, int eighths) {
     return ok;
 }
 
-size_t factor_scratch_doubles(int NP) { return (size_t)NP * NP / 4 + (size_t)NP * NP / 16 + 4096; }
+size_t factor_scratch_doubles(int NP) { return factor_scratch_doubles_of(NP); }
+
+// dst[r][c] = src[r][c], r < rows, c < cols (cols a multiple of 2): the bounce buffer of L21 back into K
+__global__ __launch_bounds__(256) void k_copy2d(const double* __restrict__ src, long lds_, double* __restrict__ dst, long ldd, int rows, int cols) {
+    const int c2 = cols / 2;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < (long)rows * c2; e += (long)gridDim.x * 256) {
+        const long r = e / c2, c = (e % c2) * 2;
+        *reinterpret_cast<d2*>(dst + r * ldd + c) = *reinterpret_cast<const d2*>(src + r * lds_ + c);
+    }
+}
+
+// Executes the plan of gpt_fit_plan.h (see there for the algebra).
+static void run_fit_plan(const FitPlan& pl, hipStream_t s, double* K, double* W, int NP, int* info, double* scratch, FitAux* aux,
+                         hipEvent_t ev_factored) {
+    bool want_side = false;
+    for (const FitOp& op : pl.ops) want_side = want_side || op.kind == FOP_FORK;
+    const bool side_ok = want_side && aux && fit_side_init(*aux);
+    const int leaf_grp = fit_env_int("GPT_FIT_LEAF_GROUP", 1);
+    for (const FitOp& op : pl.ops) {
+        const int off = op.off, n1 = op.n1, n2 = op.n2;
+        hipStream_t st = (op.side && side_ok) ? aux->side : s;
+        double* const K21 = K + (size_t)(off + n1) * NP + off;
+        double* const W11 = W + (size_t)off * NP + off;
+        switch (op.kind) {
+        case FOP_LEAF_FACTOR:
+            potrf_groups(s, K, W, NP, info, off / NB, (off + n1) / NB, (off + n1) / NB, pl.recursive ? leaf_grp : 0);
+            potrf_finish(s, K, W, NP, off / NB, (off + n1) / NB);
+            break;
+        case FOP_LEAF_INVERSE:
+            trinv_levels(s, K, W, NP, off, n1, scratch + op.r0);
+            break;
+        case FOP_FACTORED:
+            if (ev_factored) hipEventRecord(ev_factored, s);
+            break;
+        case FOP_L21: {
+            GemmArgs a{};
+            a.A = K21; a.lda = NP;                                   // A21 (n2 x n1), updated by every earlier level
+            a.B = W11; a.ldb = NP;                                   // W11 (n1 x n1, lower), used transposed
+            a.C = scratch + op.r0; a.ldc = n1;
+            a.M = a.M_last = n2; a.N = n1; a.K = a.K_last = n1; a.nbatch = 1;
+            a.alpha = 1.0; a.beta = 0.0; a.bt_lower = 1;
+            launch_gemm<true>(s, a);
+        } break;
+        case FOP_COPY_L21: {
+            const long tot = (long)n2 * n1 / 2;
+            const unsigned grid = (unsigned)((tot + 255) / 256 < 4096 ? (tot + 255) / 256 : 4096);
+            hipLaunchKernelGGL(k_copy2d, dim3(grid), dim3(256), 0, s, scratch + op.r0, (long)n1, K21, (long)NP, n2, n1);
+        } break;
+        case FOP_SYRK: {
+            GemmArgs c{};
+            c.A = scratch + op.r0; c.lda = n1;
+            c.B = c.A; c.ldb = n1;
+            c.C = K + (size_t)(off + n1) * NP + off + n1; c.ldc = NP;
+            c.M = c.M_last = n2; c.N = n2; c.K = c.K_last = n1; c.nbatch = 1;
+            c.alpha = -1.0; c.beta = 1.0; c.lower_only = 1;
+            launch_gemm<true>(s, c);
+        } break;
+        case FOP_FORK:
+            if (side_ok) { hipEventRecord(aux->side_fork[op.depth], s); hipStreamWaitEvent(aux->side, aux->side_fork[op.depth], 0); }
+            break;
+        case FOP_T21: {
+            GemmArgs a{};
+            a.A = K21; a.lda = NP;                                   // L21
+            a.B = W11; a.ldb = NP;                                   // W11 (lower)
+            a.C = scratch + op.r1; a.ldc = n1;
+            a.M = a.M_last = n2; a.N = n1; a.K = a.K_last = n1; a.nbatch = 1;
+            a.alpha = 1.0; a.beta = 0.0; a.b_lower = 1;
+            launch_gemm<false>(st, a);
+        } break;
+        case FOP_JOIN:
+            if (side_ok) { hipEventRecord(aux->side_join[op.depth], aux->side); hipStreamWaitEvent(s, aux->side_join[op.depth], 0); }
+            break;
+        case FOP_W21: {
+            GemmArgs c{};
+            c.A = W + (size_t)(off + n1) * NP + off + n1; c.lda = NP;   // W22 (n2 x n2, lower)
+            c.B = scratch + op.r1; c.ldb = n1;                          // T21
+            c.C = W + (size_t)(off + n1) * NP + off; c.ldc = NP;        // W21
+            c.M = c.M_last = n2; c.N = n1; c.K = c.K_last = n2; c.nbatch = 1;
+            c.alpha = -1.0; c.beta = 0.0; c.a_lower = 1;
+            launch_gemm<false>(s, c);
+        } break;
+        }
+    }
+}
 
 // L = chol(K) in place and W = L^-1.  `ev_factored` (may be null) is recorded in `s` once L is complete.
 //
@@ -985,6 +1108,10 @@ size_t factor_scratch_doubles(int NP) { return (size_t)NP * NP / 4 + (size_t)NP 
 // others; afterwards W22 and W21 = -W22 T21 on the whole chip.  Measured (profiles/r02_fit_overlap.log): N = 8192 10.37 ->
 // 9.66 ms; N = 6000 and 12000 unchanged; N = 16384 slower (its second half is GEMM-bound, not chain-bound) — hence the size window.
 void launch_factor_inverse(hipStream_t s, double* K, double* W, int NP, int* info, double* scratch, FitAux* aux, hipEvent_t ev_factored) {
+    {
+        const FitPlan pl = fit_plan(NP);
+        if (pl.recursive) { run_fit_plan(pl, s, K, W, NP, info, scratch, aux, ev_factored); return; }
+    }
     const int nb = NP / NB;
     const int gw = potrf_group(NP) * potrf_outer_blocks();
     int hb = nb / 2 / gw * gw;                                      // split block column, group-aligned.  NOT tunable as is: the scratch
@@ -993,7 +1120,7 @@ void launch_factor_inverse(hipStream_t s, double* K, double* W, int NP, int* inf
     const bool fits = r_split * r_split / 4 <= (size_t)NP * NP / 16 + 4096;      // its inverse's scratch (a split off the half, e.g. GPT_POTRF_GROUP=4: serial form)
     const bool overlap = NP > 4096 && NP <= 12288 && hb >= gw && fits && aux && fit_aux_init(*aux, NP <= 6144 ? 4 : 3);
     if (!overlap) {
-        potrf_groups(s, K, W, NP, info, 0, nb);
+        potrf_groups(s, K, W, NP, info, 0, nb, nb);
         potrf_finish(s, K, W, NP, 0, nb);
         if (ev_factored) hipEventRecord(ev_factored, s);
         trinv_levels(s, K, W, NP, 0, NP, scratch);
@@ -1002,12 +1129,12 @@ void launch_factor_inverse(hipStream_t s, double* K, double* W, int NP, int* inf
     const int h = hb * NB, r = NP - h;
     double* T21 = scratch;                                          // r x h, row-major
     double* inner = scratch + (size_t)NP * NP / 4;                  // scratch of the half-size inverses
-    potrf_groups(s, K, W, NP, info, 0, hb);                         // columns [0, h) final, A22 carries their update
+    potrf_groups(s, K, W, NP, info, 0, hb, nb);                     // columns [0, h) final, A22 carries their update
     hipEventRecord(aux->e_fork, s);
     hipStreamWaitEvent(aux->sa, aux->e_fork, 0);
     hipStreamWaitEvent(aux->sb, aux->e_fork, 0);
     // stream a: the rest of the factorisation
-    potrf_groups(aux->sa, K, W, NP, info, hb, nb);
+    potrf_groups(aux->sa, K, W, NP, info, hb, nb, nb);
     potrf_finish(aux->sa, K, W, NP, hb, nb);
     hipEventRecord(aux->e_a, aux->sa);
     // stream b: W11 = L11^-1, T21 = L21 W11

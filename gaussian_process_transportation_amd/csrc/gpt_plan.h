@@ -3,15 +3,18 @@
 //
 // The product V = A B has A = the stack of `ntask` block-lower-triangular inverse factors (nbi x nbi tiles of
 // 512 x 512 each; ntask = 1 for the exact GP, T for the SVGP exact-conversion model) and B = the generated kernel
-// columns, 64 per column block.  A *sweep* is (column block cb, task, i-block ib, k tiles [k_lo, k_hi)) with
-// k_hi <= ib + 1; a whole sweep has k_lo = 0, k_hi = ib + 1 and its 512 x 64 result is folded straight into the
-// per-column sums of squares.
+// columns, 64 per column block.  A *sweep* is (column block cb, task, i-block ib, k range [k_lo, k_hi)) counted in QUARTER
+// tiles (VAR_KQ per tile: 32 k4-steps, one LDS chunk of the kernel), k_hi <= 4 (ib + 1); a whole sweep has k_lo = 0,
+// k_hi = 4 (ib + 1) and its 512 x 64 result is folded straight into the per-column sums of squares.  The diagonal tile
+// [4 ib, 4 ib + 4) is never divided.
 //
 //   * Rounds: while at least P (= workgroups = CUs) column blocks are left, workgroup p takes block r P + p whole, all
 //     tasks, longest sweep first — every workgroup then walks the same tiles of A at the same time, which is what
 //     keeps the A stream in L2.  Rounds need no list: the kernel derives them from (round, blockIdx).
 //   * Tail (and every launch with fewer than P blocks — the reference's own batch sizes, M = 400 .. 10^4): the
-//     remaining sweeps are laid end to end, costed, and cut into P ranges of equal cost AT TILE GRANULARITY.  A sweep
+//     remaining sweeps are laid end to end, costed, and cut into P ranges of equal cost AT QUARTER-TILE GRANULARITY (tile
+//     granularity until round 4: with 3.2 tiles of work per workgroup — N = 2500, M = 4096 — shares of 3 and 4 tiles are 25 %
+//     apart, and the 42 tiles of configs[1]'s 14-block tail kept 42 of 256 workgroups busy).  A sweep
 //     that is cut leaves partial products: each part writes its 512 x 64 partial V to `vslab`, and k_var_combine adds
 //     the parts in order, squares and reduces.  The explicit list of items per workgroup built here is what the
 //     kernel executes.  The list is block-major: a workgroup keeps its generated B image for the following sweeps of
@@ -35,11 +38,13 @@ constexpr int VAR_SLOT = 2 * VAR_COLS;             // elements per slab slot: ss
 constexpr int VAR_VSLOT = VAR_ROWS * VAR_COLS;     // elements per vslab slot: one 512 x 64 partial product
 constexpr int VAR_DIAG_COST = 72;      // k4-steps a diagonal tile costs a SIMD (waves g and 7-g: 16 (g+1) + 16 (8-g), halved)
 constexpr int VAR_TILE_COST = 128;     // k4-steps of a full tile
+constexpr int VAR_KQ = 4;              // item k ranges count quarter tiles
+constexpr int VAR_Q_COST = VAR_TILE_COST / VAR_KQ;     // 32 k4-steps = one LDS chunk of k_var (both element types)
 constexpr int VAR_SWEEP_OVERHEAD = 6;  // fixed cost of a sweep in k4-steps (first fill, accumulator fold)
 
 struct VarItem {
     int cb, task, ib;     // column block, task, i-block
-    int k_lo, k_hi;       // k tiles [k_lo, k_hi), k_hi <= ib + 1
+    int k_lo, k_hi;       // quarter tiles [k_lo, k_hi), k_hi <= 4 (ib + 1); the diagonal tile [4 ib, 4 ib + 4) whole or not at all
     int flags;            // VI_*
     int slot;             // >= 0: after this item the running column sums go to slab slot `slot`
     int vslot;            // >= 0: partial product, stored to vslab slot `vslot` instead of being folded
@@ -78,13 +83,16 @@ struct VarPlanHost {
     int order = 0;              // 0 block-major, 1 sweep-major
 };
 
+// k_lo, k_hi in quarter tiles
 inline int var_sweep_cost(int ib, int k_lo, int k_hi) {
-    const int full_end = k_hi < ib ? k_hi : ib;
+    const int diag_lo = VAR_KQ * ib;
+    const int full_end = k_hi < diag_lo ? k_hi : diag_lo;
     int c = VAR_SWEEP_OVERHEAD;
-    if (full_end > k_lo) c += VAR_TILE_COST * (full_end - k_lo);
-    if (k_hi == ib + 1) c += VAR_DIAG_COST;
+    if (full_end > k_lo) c += VAR_Q_COST * (full_end - k_lo);
+    if (k_hi == diag_lo + VAR_KQ) c += VAR_DIAG_COST;
     return c;
 }
+inline int var_whole_sweep_cost(int ib) { return var_sweep_cost(ib, 0, VAR_KQ * (ib + 1)); }
 
 // ncols = columns of B (queries x columns per query).  order: 0 (or -1) block-major, 1 sweep-major (diagnostic).
 inline VarPlanHost build_var_plan(int64_t ncols, int nbi, int ntask, int P, int order = -1) {
@@ -101,8 +109,8 @@ inline VarPlanHost build_var_plan(int64_t ncols, int nbi, int ntask, int P, int 
     if (ncb_t == 0) return h;
 
     // ---- the tail's sweeps in execution order
-    // k1 >= 0: only the tiles [0, k1) of this sweep are laid out here; [k1, ib + 1) went to workgroup post_wg (its item
-    // post_idx) as the last partial product of the sweep
+    // k1 >= 0: only the quarter tiles [0, k1) of this sweep are laid out here; [k1, 4 (ib + 1)) went to workgroup post_wg (its
+    // item post_idx) as the last partial product of the sweep
     struct Sweep { int cbt, task, ib; int k1 = -1, post_wg = -1, post_idx = -1; };
     std::vector<Sweep> sweeps;
     sweeps.reserve((size_t)ncb_t * ntask * nbi);
@@ -120,7 +128,7 @@ inline VarPlanHost build_var_plan(int64_t ncols, int nbi, int ntask, int P, int 
     struct Contribution { bool split; int ref; };                        // ref: item index (flush) or split index
     std::vector<std::vector<Contribution>> contrib;
     std::vector<std::vector<VarItem>> wg;
-    constexpr int TOL = VAR_TILE_COST / 2;
+    constexpr int TOL = VAR_Q_COST / 2;
     // lays `sw` end to end over the workgroups [p_begin, p_begin + Pn) in Pn ranges of equal cost; U = total cost to share
     auto cut_range = [&](const std::vector<Sweep>& sw, const int p_begin, const int Pn, const int64_t U) -> int64_t {
         int p = 0;
@@ -130,15 +138,18 @@ inline VarPlanHost build_var_plan(int64_t ncols, int nbi, int ntask, int P, int 
         for (const Sweep& s : sw) {
             parts.clear();
             int k = 0;
-            const int kend = s.k1 >= 0 ? s.k1 : s.ib + 1;
+            const int kend = s.k1 >= 0 ? s.k1 : VAR_KQ * (s.ib + 1);
+            const int diag_lo = VAR_KQ * s.ib;
             while (k < kend) {
                 const int rem = var_sweep_cost(s.ib, k, kend);
                 const int64_t room = boundary(p) - cum;
                 int take = kend - k;
                 if (p < Pn - 1 && rem > room + TOL) {
-                    // tiles that fit into what is left of this workgroup's share (full tiles come first, the diagonal last)
-                    int64_t nt = (room - VAR_SWEEP_OVERHEAD + TOL) / VAR_TILE_COST;
-                    if (nt > kend - k - 1) nt = kend - k - 1;            // leave something for the next workgroup
+                    // quarter tiles that fit into what is left of this workgroup's share (full tiles come first, the diagonal
+                    // tile last and whole); something is left for the next workgroup
+                    int64_t nt = (room - VAR_SWEEP_OVERHEAD + TOL) / VAR_Q_COST;
+                    const int max_take = (kend > diag_lo ? diag_lo : kend - 1) - k;
+                    if (nt > max_take) nt = max_take;
                     if (nt < 1) { ++p; continue; }                       // nothing fits: close this workgroup
                     take = (int)nt;
                 }
@@ -169,7 +180,7 @@ inline VarPlanHost build_var_plan(int64_t ncols, int nbi, int ntask, int P, int 
     // are: the cut is repeated with the total the previous pass produced (settles after one repetition).
     auto cut_settled = [&](std::vector<Sweep>& sw, const int p_begin, const int Pn, auto&& before_each) {
         int64_t U = 0;
-        for (const Sweep& x : sw) U += var_sweep_cost(x.ib, 0, x.k1 >= 0 ? x.k1 : x.ib + 1);
+        for (const Sweep& x : sw) U += var_sweep_cost(x.ib, 0, x.k1 >= 0 ? x.k1 : VAR_KQ * (x.ib + 1));
         for (int rep = 0; rep < 4; ++rep) {
             reset();
             before_each();                       // (may set the k0 / pre_* fields of sw: the U of the first pass is then an over-estimate, corrected by the repetition)
@@ -197,14 +208,14 @@ inline VarPlanHost build_var_plan(int64_t ncols, int nbi, int ntask, int P, int 
     int best_s = 1, best_f = 0;
     if (cohorts) {
         int64_t best = -1, all = 0;
-        for (int ib = 0; ib < nbi; ++ib) all += var_sweep_cost(ib, 0, ib + 1);
+        for (int ib = 0; ib < nbi; ++ib) all += var_whole_sweep_cost(ib);
         for (int s = 1; s < nbi; ++s)
             for (int f = 0; f < s; ++f) {
                 if (f > 0 && s < 2) continue;                         // the short cohort's part needs a sweep in front of it
-                int64_t a = f ? var_sweep_cost(s - 1, s - f, s) : 0, b = var_sweep_cost(s - 1, 0, s - f);
+                int64_t a = f ? var_sweep_cost(s - 1, VAR_KQ * (s - f), VAR_KQ * s) : 0, b = var_sweep_cost(s - 1, 0, VAR_KQ * (s - f));
                 for (int ib = 0; ib < nbi; ++ib)
-                    if (ib >= s) a += var_sweep_cost(ib, 0, ib + 1);
-                    else if (ib < s - 1) b += var_sweep_cost(ib, 0, ib + 1);
+                    if (ib >= s) a += var_whole_sweep_cost(ib);
+                    else if (ib < s - 1) b += var_whole_sweep_cost(ib);
                 a *= ntask; b *= ntask;
                 const int64_t span = std::max<int64_t>(a, (b * ncb_t + nB - 1) / nB);
                 if (best < 0 || span < best) { best = span; best_s = s; best_f = f; }
@@ -228,11 +239,11 @@ inline VarPlanHost build_var_plan(int64_t ncols, int nbi, int ntask, int P, int 
             for (int c = 0; c < ncb_t; ++c)
                 for (int t = 0; t < ntask; ++t) {
                     for (int ib = nbi - 1; ib >= best_s; --ib)
-                        wg[c].push_back(VarItem{(int)d.nfull + c, t, ib, 0, ib + 1, 0, -1, -1});
+                        wg[c].push_back(VarItem{(int)d.nfull + c, t, ib, 0, VAR_KQ * (ib + 1), 0, -1, -1});
                     if (best_f > 0) {
                         Sweep& sp = shortsw[cut_at[(size_t)c * ntask + t]];
-                        sp.k1 = best_s - best_f; sp.post_wg = c; sp.post_idx = (int)wg[c].size();
-                        wg[c].push_back(VarItem{(int)d.nfull + c, t, best_s - 1, best_s - best_f, best_s, 0, -1, -1});
+                        sp.k1 = VAR_KQ * (best_s - best_f); sp.post_wg = c; sp.post_idx = (int)wg[c].size();
+                        wg[c].push_back(VarItem{(int)d.nfull + c, t, best_s - 1, VAR_KQ * (best_s - best_f), VAR_KQ * best_s, 0, -1, -1});
                     }
                 }
         });

@@ -41,6 +41,7 @@ template <> struct El<double> {
     struct AF { d2 lo, hi; };
     static __device__ __forceinline__ void lda(AF& a, const avec* __restrict__ p, const int lane) { a.lo = p[lane]; a.hi = p[lane + 64]; }
     static __device__ __forceinline__ void keep(const AF& a, const v4& b) { asm volatile("" :: "v"(a.lo), "v"(a.hi), "v"(b)); }
+    static __device__ __forceinline__ void keep1(const v4& b) { asm volatile("" :: "v"(b)); }
     static __device__ __forceinline__ v4 mfma(const double a, const double b, const v4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
     static __device__ __forceinline__ void mfma16(v4 (&acc)[4][4], const AF& a, const v4& b) {
 #pragma unroll
@@ -75,6 +76,7 @@ template <> struct El<float> {
     struct AF { f4 v; };
     static __device__ __forceinline__ void lda(AF& a, const avec* __restrict__ p, const int lane) { a.v = p[lane]; }
     static __device__ __forceinline__ void keep(const AF& a, const v4& b) { asm volatile("" :: "v"(a.v), "v"(b)); }
+    static __device__ __forceinline__ void keep1(const v4& b) { asm volatile("" :: "v"(b)); }
     static __device__ __forceinline__ v4 mfma(const float a, const float b, const v4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
     static __device__ __forceinline__ void mfma16(v4 (&acc)[4][4], const AF& a, const v4& b) {
 #pragma unroll
@@ -284,6 +286,37 @@ void launch_mean_jac(hipStream_t s, const KernelParams& p, const void* Xs, const
 #ifndef GPT_ABL
 #define GPT_ABL 0
 #endif
+// Further timing-only ablations (round 4, small models: tools/small_n_probe.py): 7 generating sweep without the exp (the
+// squared distance itself is stored), 8 no copy of the generated fragments to the scratch image, 9 no fold of the
+// accumulators into the column sums.
+// -DGPT_VAR_TRACE (make trace): shader-clock stamps (s_memtime) of every wave of two workgroups at the phase boundaries of
+// their first VT_ITEMS items, written to the buffer set through gpt_debug_set_var_trace.
+#ifndef GPT_GEN_DIAG_FREE
+#define GPT_GEN_DIAG_FREE 1      // generating sweeps: diagonal tile barrier-free after its fragments went to the scratch image
+#endif
+#ifndef GPT_GEN_BATCH_PROLOGUE
+#define GPT_GEN_BATCH_PROLOGUE 1 // generating sweeps: the first chunk's four source loads in flight together
+#endif
+#ifndef GPT_GEN_STAGED_EXP
+#define GPT_GEN_STAGED_EXP 1     // openings of a generating sweep: the four exps of a lane stage by stage
+#endif
+#ifndef GPT_DIAG_RING
+#define GPT_DIAG_RING 4          // fp64 barrier-free diagonal tile: operand ring depth (2 = the loop of rounds 1-3)
+#endif
+#ifdef GPT_VAR_TRACE
+constexpr int VT_STAMPS = 12, VT_ITEMS = 24, VT_WGS = 2;
+__device__ long long* g_var_trace = nullptr;
+// (inline asm with AMDGPU constraints has to sit in a __device__ function: in the body of a __global__ template the host
+// pass rejects the constraint, silently drops the kernel's host stub and the library no longer loads)
+static __device__ __forceinline__ long long vt_clock() {
+    long long t_;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");
+    return t_;
+}
+#define GPT_VT(i) do { if (vt_base && lane == 0 && it < VT_ITEMS) vt_base[(size_t)it * VT_STAMPS + (i)] = vt_clock(); } while (0)
+#else
+#define GPT_VT(i) do { } while (0)
+#endif
 constexpr int VAR_SUB = 8;          // k4-steps per sub-chunk (= waves per workgroup: wave w fills step w of each)
 // chunk double buffer (fp64: 2 x 32 steps x 2 KiB = 128 KiB; fp32: 64 KiB) or, fp32, the B image of a diagonal tile (128 steps x 1 KiB)
 template <typename T> constexpr size_t var_lds_bytes() {
@@ -319,6 +352,14 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
     const int D = p.D;
     auto Bs = [&](const int buf, const int step) -> T* { return Bs_dyn + ((size_t)(buf * VAR_CH + step) * 64 + lane) * 4; };
     if (std::is_same<T, double>::value && threadIdx.x < 256) Tt[threadIdx.x] = g_exp2_table[threadIdx.x];
+#ifdef GPT_VAR_TRACE
+    long long* vt_base = nullptr;
+    if (g_var_trace && (blockIdx.x == 0 || blockIdx.x == 37))
+        vt_base = g_var_trace + ((size_t)(blockIdx.x == 0 ? 0 : 1) * 8 + w) * VT_ITEMS * VT_STAMPS;
+    // begin / end clock of every workgroup (wave 0), behind the phase stamps: [VT_WGS * 8 * VT_ITEMS * VT_STAMPS + 2 * blockIdx.x]
+    long long* const vt_wg = (g_var_trace && threadIdx.x == 0 && blockIdx.x < 1024) ? g_var_trace + (size_t)VT_WGS * 8 * VT_ITEMS * VT_STAMPS + 2 * blockIdx.x : nullptr;
+    if (vt_wg) vt_wg[0] = vt_clock();
+#endif
 
     constexpr T RS2 = (T)0.70710678118654752440;    // coordinates are pre-scaled by 1/sqrt(2): t = ln c - |d'|^2
     // NCOMP=4: column = 4 query + comp, comp = lc & 3 in every tile: b = kv * (cbv + sum_d cd[d] * d'_d).
@@ -360,7 +401,7 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
             task = r / nbi;
             ib = nbi - 1 - (r - task * nbi);
             cb = rnd * pl.P + blockIdx.x;
-            k_lo = 0; k_hi = ib + 1;
+            k_lo = 0; k_hi = VAR_KQ * (ib + 1);
             flags = (r == 0 ? (VI_FIRST | VI_GEN) : 0) | (ib == nbi - 1 ? VI_ZERO : 0);
             slot = (ib == 0) ? (int)(cb * pl.ntask + task) : -1;
             vslot = -1;
@@ -371,6 +412,7 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
             cb = item.cb; task = item.task; ib = item.ib; k_lo = item.k_lo; k_hi = item.k_hi;
             flags = item.flags; slot = item.slot; vslot = item.vslot;
         }
+        GPT_VT(0);
         if (flags & VI_FIRST) {
             __syncthreads();                               // LDS (Bs, red, Tt) free / ready
             // the scratch image is about to be rewritten: drop the L1 lines of it this CU may still hold
@@ -393,6 +435,7 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
 #pragma unroll
             for (int t = 0; t < 4; ++t) { ssq[t] = (T)0; crs[t] = (T)0; }
         }
+        GPT_VT(1);
         const int base3 = (NCOMP == 3) ? (int)((cb * VAR_COLS + lc) % D) : 0;
         const T sc3[3] = {(T)(p.inv_ls[0] * 1.41421356237309504880), (T)(p.inv_ls[1] * 1.41421356237309504880),
                           (T)(p.inv_ls[2] * 1.41421356237309504880)};
@@ -417,24 +460,31 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
             T gx[DW];                                      // coordinates of the source this wave generates next
             T gx_own = (T)0;                               // (wide) and the one a derivative column multiplies by
             v4 bl;                                         // or the fragments it reloads next
-            auto load_x = [&](const T* xp) {
+            auto load_x_to = [&](const T* xp, T (&ox)[DW], T& oown) {
                 if constexpr (WIDE) {
 #pragma unroll
                     for (int v = 0; v < DW / 4; ++v) {
                         const v4 xv = *reinterpret_cast<const v4*>(xp + 4 * v);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) gx[4 * v + e] = xv[e];
+                        for (int e = 0; e < 4; ++e) ox[4 * v + e] = xv[e];
                     }
-                    if (NCOMP != 1) gx_own = xp[own_d];
+                    if (NCOMP != 1) oown = xp[own_d];
                 } else {
-                    gx[0] = xp[0]; gx[1] = xp[1]; gx[2] = xp[2];
+                    ox[0] = xp[0]; ox[1] = xp[1]; ox[2] = xp[2];
                 }
             };
+            auto load_x = [&](const T* xp) { load_x_to(xp, gx, gx_own); };
             auto fetch = [&](const int k4) {
                 if (GEN) load_x(Xs + (size_t)(k4 * 4 + lk) * XS);
                 else bl = (buni + (size_t)k4 * 64)[lane];
             };
-            auto produce = [&](const int buf, const int k4) {   // B fragments of k-step k4 -> LDS (+ scratch)
+            // B fragments of k-step k4 -> LDS chunk buffer `buf` (to_lds) and, when generated, the scratch image
+            // staged: the four exps of a lane stage by stage (gpt_exp.h kernel_tab4: their latencies overlap — the openings of a
+            // sweep, where no MFMA hides them); not staged: one after the other, as few live registers as possible (inside the
+            // MFMA loop, where the staged form spills)
+            auto produce_to = [&](auto lds_tag, auto staged_tag, const int buf, const int k4) {
+                constexpr bool to_lds = decltype(lds_tag)::value;
+                constexpr bool staged = decltype(staged_tag)::value;
                 T* dstl = Bs(buf, k4 % VAR_CH);
                 if constexpr (GEN && WIDE) {
                     T x[DW];
@@ -442,53 +492,112 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
                     for (int d = 0; d < DW; ++d) x[d] = gx[d] * RS2;
                     const T xo = gx_own * RS2;
                     v4 b;
+                    T hh[4], kv[4];
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const int qi = (16 * t + lc) / (CPQ > 1 ? CPQ : 1);      // this column's query within the block
                         T df = x[0] - qs[0][qi];
-                        T hh = df * df;
+                        hh[t] = df * df;
 #pragma unroll
-                        for (int d = 1; d < DW; ++d) { df = x[d] - qs[d][qi]; hh = fma(df, df, hh); }
-                        const T kv = kernel_tab<KT>(hh, lnc, Tt);
-                        b[t] = (NCOMP == 1) ? kv : kv * (cbv + sc_own * (xo - qs[own_d][qi]));
+                        for (int d = 1; d < DW; ++d) { df = x[d] - qs[d][qi]; hh[t] = fma(df, df, hh[t]); }
                     }
-                    *reinterpret_cast<v4*>(dstl) = b;
+                    if constexpr (staged) kernel_tab4<KT>(hh, lnc, Tt, kv);
+                    else {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) kv[t] = kernel_tab<KT>(hh[t], lnc, Tt);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int qi = (16 * t + lc) / (CPQ > 1 ? CPQ : 1);
+                        b[t] = (NCOMP == 1) ? kv[t] : kv[t] * (cbv + sc_own * (xo - qs[own_d][qi]));
+                    }
+                    if (to_lds) *reinterpret_cast<v4*>(dstl) = b;
                     (buni + (size_t)k4 * 64)[lane] = b;
                 } else if (GEN) {
                     const T x0 = gx[0] * RS2, x1 = gx[1] * RS2, x2 = gx[2] * RS2;
                     v4 b;
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const T d0 = x0 - q[t][0], d1 = x1 - q[t][1], d2_ = x2 - q[t][2];
-                        T hh = d0 * d0;
-                        hh = fma(d1, d1, hh);
-                        hh = fma(d2_, d2_, hh);
-                        const T kv = kernel_tab<KT>(hh, lnc, Tt);
+                    auto column = [&](const int t, const T kv, const T d0, const T d1, const T d2_) -> T {
                         if (NCOMP == 3) {
                             int dsel = base3 + ((D == 3) ? t : 0);            // (64 cb + 16 t + lc) mod D, base3 = (64 cb + lc) mod D
                             dsel = (dsel >= D) ? dsel - D : dsel;
                             const T e = (dsel == 0) ? d0 * sc3[0] : ((dsel == 1) ? d1 * sc3[1] : d2_ * sc3[2]);
-                            b[t] = kv * e;
+                            return kv * e;
+                        }
+                        return (NCOMP == 1) ? kv : kv * (cbv + cd[0] * d0 + cd[1] * d1 + cd[2] * d2_);
+                    };
+                    if constexpr (staged) {
+                        T d0[4], d1[4], d2_[4], hh[4], kv[4];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            d0[t] = x0 - q[t][0]; d1[t] = x1 - q[t][1]; d2_[t] = x2 - q[t][2];
+                            hh[t] = d0[t] * d0[t];
+                            hh[t] = fma(d1[t], d1[t], hh[t]);
+                            hh[t] = fma(d2_[t], d2_[t], hh[t]);
+                        }
+                        if (GPT_ABL == 7) {
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) kv[t] = hh[t];
                         } else {
-                            b[t] = (NCOMP == 1) ? kv : kv * (cbv + cd[0] * d0 + cd[1] * d1 + cd[2] * d2_);
+                            kernel_tab4<KT>(hh, lnc, Tt, kv);
+                        }
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) b[t] = column(t, kv[t], d0[t], d1[t], d2_[t]);
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const T d0 = x0 - q[t][0], d1 = x1 - q[t][1], d2_ = x2 - q[t][2];
+                            T hh = d0 * d0;
+                            hh = fma(d1, d1, hh);
+                            hh = fma(d2_, d2_, hh);
+                            const T kv = (GPT_ABL == 7) ? hh : kernel_tab<KT>(hh, lnc, Tt);
+                            b[t] = column(t, kv, d0, d1, d2_);
                         }
                     }
-                    *reinterpret_cast<v4*>(dstl) = b;
-                    (buni + (size_t)k4 * 64)[lane] = b;
+                    if (to_lds) *reinterpret_cast<v4*>(dstl) = b;
+                    if (GPT_ABL != 8) (buni + (size_t)k4 * 64)[lane] = b;
                 } else {
                     *reinterpret_cast<v4*>(dstl) = bl;
                 }
             };
+            auto produce = [&](const int buf, const int k4) { produce_to(std::true_type{}, std::false_type{}, buf, k4); };
+            // GEN: `cnt` k-steps k4_0 + j * stride generated with their source loads in flight together (load -> wait -> exp ->
+            // store one at a time cost 9.5 k cycles per k-step at the opening of a sweep: profiles/r04_small_n.txt)
+            auto generate_batch = [&](auto lds_tag, auto cnt_tag, const int buf, const int k4_0, const int stride) {
+                constexpr int cnt = decltype(cnt_tag)::value;
+                T bx[cnt][DW], bo[cnt];
+#pragma unroll
+                for (int j = 0; j < cnt; ++j) { bo[j] = (T)0; load_x_to(Xs + (size_t)((k4_0 + j * stride) * 4 + lk) * XS, bx[j], bo[j]); }
+#pragma unroll
+                for (int j = 0; j < cnt; ++j) {
+#pragma unroll
+                    for (int d = 0; d < DW; ++d) gx[d] = bx[j][d];
+                    gx_own = bo[j];
+                    produce_to(lds_tag, std::integral_constant<bool, GPT_GEN_STAGED_EXP != 0>{}, buf, k4_0 + j * stride);
+                }
+            };
 
             const size_t S_ib = (size_t)task * pl.tiles_per_task * WT_K4 + (size_t)64 * ib * (ib + 1);   // stream index of k4-step 0 of this i-block
-            const bool has_diag = (k_hi == ib + 1);
-            const int K0 = k_lo * WT_K4;                                       // first k4-step of this item
-            // Reload sweeps take the diagonal tile (where wave g only has 16 (g + 1) steps of work) OUT of the lock-step
-            // LDS pipeline: see below.  A generating sweep keeps it in (its fragments are not in the scratch image yet).
-            const int lock_end = ((GEN || !has_diag) ? k_hi : ib) * WT_K4;
+            static_assert(VAR_CH == VAR_Q_COST && WT_K4 == VAR_KQ * VAR_CH, "an item's k range counts LDS chunks (quarter tiles)");
+            const bool has_diag = (k_hi == VAR_KQ * (ib + 1));                 // (the diagonal tile is never divided: gpt_plan.h)
+            const int K0 = k_lo * VAR_CH;                                      // first k4-step of this item
+            // The diagonal tile (where wave g only has 16 (g + 1) steps of work) runs OUT of the lock-step LDS pipeline: see
+            // below.  A generating sweep first puts that tile's fragments into the scratch image (GEN_DIAG_FREE; until round 4 it
+            // kept the tile inside the lock-step part, where it costs 0.75 of a full tile instead of 0.56).
+            constexpr bool DIAG_FREE = !GEN || GPT_GEN_DIAG_FREE != 0;
+            const int lock_end = ((!DIAG_FREE || !has_diag) ? k_hi : VAR_KQ * ib) * VAR_CH;
             const int ch0 = K0 / VAR_CH, ch1 = lock_end / VAR_CH;              // lock-step chunks [ch0, ch1)
+            if (GEN && DIAG_FREE && has_diag && GPT_ABL != 3) {
+                // 128 k-steps, 16 per wave (w, w + 8, ...), VALU only; complete and visible before the barrier below
+                const int kd0 = ib * WT_K4;
+#pragma unroll 1
+                for (int j0 = 0; j0 < 16; j0 += 4)
+                    generate_batch(std::false_type{}, std::integral_constant<int, 4>{}, 0, kd0 + w + VAR_SUB * j0, VAR_SUB);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             if (ch1 > ch0) {                                  // first chunk: wave w fills steps w, w+8, w+16, w+24
-                if (!GEN && El<T>::BATCH_PROLOGUE) {
+                if (GEN && GPT_GEN_BATCH_PROLOGUE != 0) {
+                    generate_batch(std::true_type{}, std::integral_constant<int, VAR_SUBS>{}, ch0 & 1, K0 + w, VAR_SUB);
+                } else if (!GEN && El<T>::BATCH_PROLOGUE) {
                     // the four reloads in flight together instead of load -> wait -> write four times (short fp32 sweeps:
                     // 12 per block at configs[4], each opening with this latency)
                     v4 pre[VAR_SUBS];
@@ -504,12 +613,14 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
                     }
                 }
             }
+            GPT_VT(2);
             constexpr int PF = El<T>::PF;                  // divides VAR_SUB, so step s of every sub-chunk uses ring slot s % PF
             AF a_ring[PF];                                 // A fragments of the next PF steps
 #pragma unroll
             for (int i = 0; i < PF; ++i)                   // the first 16 steps of an item are active for every group
                 El<T>::lda(a_ring[i], wuni + (S_ib + K0 + i) * A_STEP, lane);
             __syncthreads();
+            GPT_VT(3);
             v4 acc[4][4];
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -573,8 +684,9 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
             };
             for (int ch = ch0; ch + 1 < ch1; ++ch) chunk(std::true_type{}, ch);
             if (ch1 > ch0) chunk(std::false_type{}, ch1 - 1);
-            if (!GEN && has_diag && GPT_ABL != 3) {
-                // Diagonal tile of a reload sweep, barrier-free: every wave runs its own 16 (g + 1) k-steps on its own.  No
+            GPT_VT(4);
+            if (DIAG_FREE && has_diag && GPT_ABL != 3) {
+                // Diagonal tile, barrier-free: every wave runs its own 16 (g + 1) k-steps on its own.  No
                 // lock-step, so the waves with g and 7 - g that share a SIMD add up to the same work on every SIMD: the tile
                 // costs 0.56 of a full one instead of the 0.75 it costs inside the lock-step pipeline.
                 const int kd0 = ib * WT_K4;                              // first k-step of the diagonal tile
@@ -626,22 +738,43 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
                         const int kk = k < limit ? k : limit - 1;
                         b = (bp + (size_t)kk * 64)[lane];
                     };
-                    AF a0, a1;
-                    v4 b0, b1;
-                    ldA(a0, 0); ldA(a1, 1); ldB(b0, 0);
-                    for (int k4 = 0; k4 < limit; k4 += 2) {
-                        ldB(b1, k4 + 1);
-                        __builtin_amdgcn_sched_barrier(0);
-                        El<T>::mfma16(acc, a0, b0);
-                        __builtin_amdgcn_sched_barrier(0);
-                        ldA(a0, k4 + 2); ldB(b0, k4 + 2);
-                        __builtin_amdgcn_sched_barrier(0);
-                        El<T>::mfma16(acc, a1, b1);
-                        __builtin_amdgcn_sched_barrier(0);
-                        ldA(a1, k4 + 3);
+                    constexpr int R = GPT_DIAG_RING;                     // 2: the round-1 .. 3 loop, kept for A/B
+                    if constexpr (R == 2) {
+                        AF a0, a1;
+                        v4 b0, b1;
+                        ldA(a0, 0); ldA(a1, 1); ldB(b0, 0);
+                        for (int k4 = 0; k4 < limit; k4 += 2) {
+                            ldB(b1, k4 + 1);
+                            __builtin_amdgcn_sched_barrier(0);
+                            El<T>::mfma16(acc, a0, b0);
+                            __builtin_amdgcn_sched_barrier(0);
+                            ldA(a0, k4 + 2); ldB(b0, k4 + 2);
+                            __builtin_amdgcn_sched_barrier(0);
+                            El<T>::mfma16(acc, a1, b1);
+                            __builtin_amdgcn_sched_barrier(0);
+                            ldA(a1, k4 + 3);
+                        }
+                    } else {
+                        // Both operands R - 1 MFMA blocks ahead.  A wave alone on its SIMD (g = 7 for 112 of its 128 steps) has
+                        // 1024 cycles per block, and the B image of a small model's block comes from beyond L2 (32 workgroups x
+                        // 0.5 MB per XCD at N = 1024): one block ahead such a wave ran at 1490 cycles per step (r04_small_n.txt).
+                        AF a[R];
+                        v4 b[R];
+#pragma unroll
+                        for (int i = 0; i < R; ++i) { ldA(a[i], i); ldB(b[i], i); }
+                        for (int k4 = 0; k4 < limit; k4 += R) {           // limit is a multiple of 16, R divides 16
+#pragma unroll
+                            for (int i = 0; i < R; ++i) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                El<T>::mfma16(acc, a[i], b[i]);
+                                __builtin_amdgcn_sched_barrier(0);
+                                ldA(a[i], k4 + i + R); ldB(b[i], k4 + i + R);
+                            }
+                        }
                     }
                 }
             }
+            GPT_VT(5);
             if (vslot >= 0) {
                 // cut sweep: this part's 512 x 64 partial product goes to vslab, [vslot][wave][r*4+t][lane] (k_var_combine)
                 v4* dst = reinterpret_cast<v4*>(vslab) + ((size_t)vslot * 8 + w) * (16 * 64) + lane;
@@ -649,7 +782,7 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
                     for (int t = 0; t < 4; ++t) dst[(r * 4 + t) * 64] = acc[r][t];
-            } else {
+            } else if (GPT_ABL != 9) {
                 // whole sweep: fold this wave's 64 rows of V into the per-column sums
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
@@ -661,7 +794,13 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
                             ssq[t] += v * v;
                             if (CROSS) crs[t] += v * __shfl(v, lane & ~(CPQ - 1));
                         }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) El<T>::keep1(acc[r][t]);
             }
+            GPT_VT(6);
         };
 
         if (flags & VI_GEN) {
@@ -672,6 +811,7 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
         } else {
             sweep(std::false_type{});
         }
+        GPT_VT(7);
 
         if (slot >= 0) {
             // rows of a column are spread over the 4 lane groups lk = 0..3 and over the 8 waves
@@ -698,7 +838,11 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
                 slab[(size_t)slot * VAR_SLOT + threadIdx.x] = v;
             }
         }
+        GPT_VT(8);
     }
+#ifdef GPT_VAR_TRACE
+    if (vt_wg) vt_wg[1] = vt_clock();
+#endif
 }
 
 // A sweep the work split cut along k: add its parts' partial products in part order, then square / reduce as the
@@ -904,3 +1048,11 @@ void launch_var(hipStream_t s, const KernelParams& p, const VarWorkspace& ws, co
 }
 
 }  // namespace gpt
+
+#ifdef GPT_VAR_TRACE
+// trace builds only (make trace): dev_buf holds VT_WGS * 8 * VT_ITEMS * VT_STAMPS int64, or NULL to switch the trace off
+extern "C" int gpt_debug_set_var_trace(void* dev_buf) {
+    long long* p = static_cast<long long*>(dev_buf);
+    return hipMemcpyToSymbol(HIP_SYMBOL(gpt::g_var_trace), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#endif

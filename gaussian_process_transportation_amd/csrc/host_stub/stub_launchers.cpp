@@ -3,6 +3,7 @@
 // checks the buffer sizing of the host orchestration (staging, model blob, slab / vslab / scratch of the variance plan).
 #include "../gpt_common.h"
 #include "../gpt_plan.h"
+#include "../gpt_fit_plan.h"
 
 namespace gpt {
 
@@ -28,9 +29,17 @@ void launch_scale_x(hipStream_t, const double* X, int N, int NP, int D, const do
 void launch_dot(hipStream_t, const double* a, const double* b, int64_t n, double* out) { touch_r(a, (size_t)n * 8); touch_r(b, (size_t)n * 8); *out = 0.0; }
 void launch_add_lower(hipStream_t, double* K, const double* S, int N, int NP) { touch_r(S, (size_t)N * N * 8); touch_w(K, (size_t)NP * NP * 8); }
 void fit_aux_release(FitAux&) {}
-size_t factor_scratch_doubles(int NP) { return (size_t)NP * NP / 4 + (size_t)NP * NP / 16 + 4096; }
+size_t factor_scratch_doubles(int NP) { return factor_scratch_doubles_of(NP); }
+// replays the plan's scratch regions (gpt_fit_plan.h) — and the non-recursive forms' whole-matrix inverse — inside the buffer
+// the orchestration allocated with factor_scratch_doubles
 void launch_factor_inverse(hipStream_t, double* K, double* W, int NP, int* info, double* scratch, FitAux*, hipEvent_t) {
-    touch_w(K, (size_t)NP * NP * 8); touch_w(W, (size_t)NP * NP * 8); touch_w(scratch, factor_scratch_doubles(NP) * 8); *info = 0;
+    touch_w(K, (size_t)NP * NP * 8); touch_w(W, (size_t)NP * NP * 8); *info = 0;
+    const FitPlan pl = fit_plan(NP);
+    if (!pl.recursive) { touch_w(scratch, ((size_t)NP * NP / 4 + (size_t)NP * NP / 16) * 8); return; }
+    for (const FitOp& op : pl.ops) {
+        if (op.r0_size) touch_w(scratch + op.r0, op.r0_size * 8);
+        if (op.r1_size) touch_w(scratch + op.r1, op.r1_size * 8);
+    }
 }
 void launch_alpha(hipStream_t, const double* W, const double* Y4, int, int NP, double* tmp4, double* A4, double* scratch) {
     touch_r(W, (size_t)NP * NP * 8); touch_r(Y4, (size_t)NP * 32); touch_w(tmp4, (size_t)NP * 32); touch_w(A4, (size_t)NP * 32);

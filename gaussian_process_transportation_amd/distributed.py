@@ -32,12 +32,19 @@ def wrap_device_bytes(ptr: int, nbytes: int, device):
     return torch.as_tensor(_DeviceBytes(ptr, nbytes), device=device)
 
 
-def broadcast_geometry(geom, src=0, group=None):
-    """Broadcast (N, D, O, tasks, element type) from `src` (CPU-side object collective; tiny)."""
+def broadcast_geometry(geom, src=0, group=None, device=None):
+    """Broadcast (N, D, O, tasks, element type) from `src` as ONE 5-element int64 tensor (no pickling: under the nccl
+    backend an object collective would serialise through a device byte tensor).  The tensor lives where the backend
+    moves data: on `device` (default: the current CUDA device) under nccl = RCCL, on the host under gloo."""
+    import torch
     import torch.distributed as dist
-    box = [tuple(int(v) for v in geom) if geom is not None else None]
-    dist.broadcast_object_list(box, src=src, group=group)
-    return box[0]
+    on_gpu = dist.get_backend(group) == "nccl"
+    dev = (device if device is not None else torch.device("cuda", torch.cuda.current_device())) if on_gpu else torch.device("cpu")
+    t = torch.zeros(5, dtype=torch.int64, device=dev)
+    if geom is not None:
+        t.copy_(torch.tensor([int(v) for v in geom], dtype=torch.int64))
+    dist.broadcast(t, src=src, group=group)
+    return tuple(int(v) for v in t.cpu().tolist())
 
 
 def broadcast_model(handle, fitted: bool, src=0, group=None, device=None):
@@ -52,7 +59,7 @@ def broadcast_model(handle, fitted: bool, src=0, group=None, device=None):
             raise RuntimeError("broadcast_model: source rank has no fitted model")
         N, D, O, _ = handle.info()
         geom = (N, D, O) + tuple(handle.model_info())          # + (tasks, element type)
-    N, D, O, n_tasks, dtype = broadcast_geometry(geom, src=src, group=group)
+    N, D, O, n_tasks, dtype = broadcast_geometry(geom, src=src, group=group, device=device)
     if rank == src:
         ptr, nbytes = handle.factor_blob()
     else:

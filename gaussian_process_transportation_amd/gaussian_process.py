@@ -80,17 +80,22 @@ class _FittedView:
 
 class GaussianProcess:
     def __init__(self, kernel, alpha=1e-10, optimizer="fmin_l_bfgs_b", n_restarts_optimizer=5, n_targets=None,
-                 device=0, verbose=True, dtype="float64"):
-        """Arguments as the reference's (:17-23); `device`, `verbose` and `dtype` are additions.  dtype="float32" keeps
-        the fp64 factorisation and runs the prediction kernels in fp32 (outputs float32; return_cov / samples need
-        float64): twice the fp64 rate, ~1e-4 of the output scale."""
+                 device=0, verbose=True, dtype="float64", devices=None):
+        """Arguments as the reference's (:17-23); `device`, `devices`, `verbose` and `dtype` are additions.  dtype="float32"
+        keeps the fp64 factorisation and runs the prediction kernels in fp32 (outputs float32; return_cov / samples need
+        float64): twice the fp64 rate, ~1e-4 of the output scale.  devices=[0, 1, ...] (default: the one `device`): the fit
+        and the hyper-parameter search run on devices[0], the fitted model is copied to the others and predict / derivative
+        / derivative_of_variance shard their rows over all of them (device_group.py) — same results, same call."""
         self._kernel_in = kernel
         self.kernel = kernel
         self.alpha = alpha
         self.optimizer = optimizer
         self.n_restarts_optimizer = n_restarts_optimizer if optimizer is not None else 0
         self.n_targets = n_targets
-        self.device = device
+        self.devices = [int(d) for d in devices] if devices is not None else None
+        if self.devices is not None and not self.devices:
+            raise ValueError("devices must name at least one GPU")
+        self.device = self.devices[0] if self.devices else device
         self.verbose = verbose
         if np.dtype(dtype) not in (np.dtype(np.float64), np.dtype(np.float32)):
             raise ValueError("dtype must be float64 or float32")
@@ -124,7 +129,11 @@ class GaussianProcess:
             from .hyperopt import optimize_hyperparameters
             c, ls, noise, lml = optimize_hyperparameters(self, c, ls, noise)
         if self._handle is None:
-            self._handle = _lib.Handle(self.device)
+            if self.devices is not None and len(self.devices) > 1:
+                from .device_group import DeviceGroup
+                self._handle = DeviceGroup(self.devices)
+            else:
+                self._handle = _lib.Handle(self.device)
         self._handle.set_dtype(self._dtype)
         self._handle.fit(self.X, self.Y, ls, c, noise, self.alpha, self._ktype)
         self._K_inv = None

@@ -23,9 +23,11 @@ def _reference_default_kernel():
 
 
 class GaussianProcessTransportation:
-    def __init__(self, kernel_transport=None, optimizer="fmin_l_bfgs_b", device=0, verbose=True):
+    def __init__(self, kernel_transport=None, optimizer="fmin_l_bfgs_b", device=0, verbose=True, devices=None):
+        """`devices=[0, 1, ...]`: apply_transportation() shards the demonstration's rows over these GPUs (the fit stays on
+        devices[0]); default: the one `device`."""
         kernel = _reference_default_kernel() if kernel_transport is None else kernel_transport
-        regressor = GaussianProcess(kernel=kernel, optimizer=optimizer, device=device, verbose=verbose)
+        regressor = GaussianProcess(kernel=kernel, optimizer=optimizer, device=device, verbose=verbose, devices=devices)
         self.method = PolicyTransportation(regressor, verbose=verbose)
 
     def _input(self, name):

@@ -179,6 +179,13 @@ int gpt_factor_alloc(gpt_handle* h, int64_t N, int D, int O, void** dev_ptr, siz
 /* The same for any model: n_tasks = 1 and GPT_F64 for gpt_fit*, (T, dtype) for gpt_fit_svgp — see gpt_model_info. */
 int gpt_factor_alloc_model(gpt_handle* h, int64_t N, int D, int O, int n_tasks, int dtype, void** dev_ptr, size_t* bytes);
 int gpt_factor_commit(gpt_handle* h);
+/* The same hand-off inside ONE process (a handle per GPU, SURVEY section 8b's n_devices): copies src's fitted model
+ * blob to dst's device (hipMemcpyPeerAsync over xGMI; a device-to-device copy when both handles sit on one GPU) and
+ * commits it.  Afterwards dst predicts exactly what src predicts.  What GaussianProcess(devices=[...]) calls after fit so
+ * that predict / derivative (gaussian_process.py:46-55, 63-102) can shard their rows over the GPUs behind the same class
+ * (transportation/gaussian_process_transportation.py:19-26 never sees the devices).  dst's fit-side state (L, W) is not
+ * copied: export / return_cov / LML stay with the handle that ran the fit. */
+int gpt_factor_copy(gpt_handle* dst, gpt_handle* src);
 
 /* Model geometry of a fitted / committed handle. */
 int gpt_info(gpt_handle* h, int64_t* N, int* D, int* O, int64_t* N_padded);
@@ -204,6 +211,12 @@ int gpt_predict_timings(gpt_handle* h, double* ms_out);
  * call) or hold item_begin[n_workgroups + 1], items[counts[0]][8], fin[counts[6]][2], splits[counts[1]][3]. */
 int gpt_debug_var_plan(int64_t n_columns, int n_iblocks, int n_tasks, int n_workgroups, int order, int64_t* counts,
                        int* item_begin, int* items, int* fin, int* splits);
+
+/* Test hook (host only, no GPU): the plan of the recursive factor + inverse for a padded size (csrc/gpt_fit_plan.h).
+ * leaf / rec_min / fork_min < 0: environment or defaults.  counts[5] = {ops, arena doubles, recursive?, depth, doubles
+ * the fit workspace allocates (>= arena)}; ops (may be NULL) receives counts[0] rows of 10: kind, side, depth, off, n1,
+ * n2, r0, r0_size, r1, r1_size (regions in doubles inside the arena; FitOpKind in gpt_fit_plan.h). */
+int gpt_debug_fit_plan(int n_padded, int leaf, int rec_min, int fork_min, int64_t* counts, int64_t* ops);
 
 #ifdef __cplusplus
 }

@@ -63,6 +63,29 @@ for N, D, O in ((1, 1, 1), (700, 3, 3), (1100, 2, 6), (530, 5, 5), (200, 8, 2), 
         h.fit_timings()
 h.set_dtype(_lib.GPT_F64)
 
+# a size the recursive factor + inverse runs at (csrc/gpt_fit_plan.h): the stand-in replays every scratch region of the plan
+# inside the arena the orchestration allocated — with the plan changing under the handle between two fits
+import os
+for leaf in ("512", "2048", None):
+    if leaf is None:
+        os.environ.pop("GPT_FIT_LEAF", None)
+    else:
+        os.environ["GPT_FIT_LEAF"] = leaf
+    Xb = rng.uniform(0, 1, (4200, 3))
+    h.fit(Xb, rng.standard_normal((4200, 2)), np.full(3, 0.3), 1.0, 1e-2, 1e-10)
+    assert _lib.debug_fit_plan(4608)["recursive"]
+h2 = _lib.Handle(0)
+h2.factor_copy_from(h)                      # one-process replica (gpt_factor_copy)
+assert h2.info() == h.info() and h2.model_info() == h.model_info()
+h2.predict_all(rng.uniform(0, 1, (300, 3)), mean=True, var=True, J=True)
+for bad in (lambda: h2.export(want_alpha=False), lambda: h2.factor_copy_from(h2), lambda: _lib.Handle(0).factor_copy_from(_lib.Handle(0))):
+    try:
+        bad()
+    except (ValueError, _lib.GptError):
+        continue
+    raise AssertionError("an invalid hand-off went through")
+h2.close()
+
 # multi-task model + hand-off to a second handle
 Z, T, D = 600, 3, 3
 Zp = rng.uniform(0, 1, (Z, D)); A = rng.standard_normal((T, Z, Z)); Sigma = A @ A.transpose(0, 2, 1) / Z + 1e-3 * np.eye(Z)

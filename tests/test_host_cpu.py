@@ -162,7 +162,7 @@ def _gloo_worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        geom = broadcast_geometry((8192, 3, 3) if rank == 0 else None, src=0)
+        geom = broadcast_geometry((8192, 3, 3, 1, 0) if rank == 0 else None, src=0)
         M = 1001
         a, b = shard_range(M, rank, world)
         full = np.arange(M * 3, dtype=np.float64).reshape(M, 3)
@@ -186,7 +186,7 @@ def test_two_rank_gloo_shard_and_gather():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert res == [(0, (8192, 3, 3), True), (1, (8192, 3, 3), True)]
+    assert res == [(0, (8192, 3, 3, 1, 0), True), (1, (8192, 3, 3, 1, 0), True)]
 
 
 def _run_bench(*argv, env_extra=None):
@@ -281,7 +281,8 @@ def _check_var_plan(cols, nbi, nt, P, order):
     ncb, nfull = pl["ncb"], pl["nfull"]
     assert ncb == -(-cols // 64) and nfull == ncb // P * P
     ncb_t = ncb - nfull
-    cover = np.zeros((max(ncb_t, 1), nt, nbi, nbi), dtype=np.int64)
+    KQ = 4                                # item k ranges count quarter tiles (gpt_plan.h VAR_KQ)
+    cover = np.zeros((max(ncb_t, 1), nt, nbi, KQ * nbi), dtype=np.int64)
     slot_sweeps = {}                      # slab slot -> [(cb, task, ib)] folded into it
     vslot_part = {}                       # vslab slot -> (cb, task, ib, k_lo, k_hi)
     cost = np.zeros(P)
@@ -290,7 +291,8 @@ def _check_var_plan(cols, nbi, nt, P, order):
     for p in range(P):
         cur_cb, generated, running = None, set(), None
         for cb, task, ib, k_lo, k_hi, flags, slot, vslot in pl["items"][ib_[p]:ib_[p + 1]]:
-            assert nfull <= cb < ncb and 0 <= task < nt and 0 <= ib < nbi and 0 <= k_lo < k_hi <= ib + 1
+            assert nfull <= cb < ncb and 0 <= task < nt and 0 <= ib < nbi and 0 <= k_lo < k_hi <= KQ * (ib + 1)
+            assert k_hi <= KQ * ib or (k_hi == KQ * (ib + 1) and k_lo <= KQ * ib), "the diagonal tile must not be divided"
             if cb != cur_cb:
                 assert flags & VI_FIRST, "a new column block must drop the previous scratch image"
                 cur_cb, generated = cb, set()
@@ -300,12 +302,12 @@ def _check_var_plan(cols, nbi, nt, P, order):
             else:
                 assert tiles <= generated, "reload of B fragments this workgroup never generated for this block"
             cover[cb - nfull, task, ib, k_lo:k_hi] += 1
-            cost[p] += 128 * (min(k_hi, ib) - k_lo) + (72 if k_hi == ib + 1 else 0)
+            cost[p] += 32 * max(min(k_hi, KQ * ib) - k_lo, 0) + (72 if k_hi == KQ * (ib + 1) else 0)
             if vslot >= 0:
                 assert slot < 0 and vslot not in vslot_part
                 vslot_part[vslot] = (cb, task, ib, k_lo, k_hi)
             else:
-                assert (k_lo, k_hi) == (0, ib + 1), "only whole sweeps may be folded into column sums"
+                assert (k_lo, k_hi) == (0, KQ * (ib + 1)), "only whole sweeps may be folded into column sums"
                 if flags & VI_ZERO:
                     assert not running, "column sums dropped without a flush"
                     running = []
@@ -318,13 +320,13 @@ def _check_var_plan(cols, nbi, nt, P, order):
                     running = None
         assert not running, "workgroup ends with unflushed column sums"
     if ncb_t:
-        want = np.tril(np.ones((nbi, nbi), dtype=np.int64))[None, None]          # [ib][k]: k <= ib
+        want = np.repeat(np.tril(np.ones((nbi, nbi), dtype=np.int64)), KQ, axis=1)[None, None]      # [ib][quarter]: quarter < 4 (ib + 1)
         assert np.array_equal(cover, np.broadcast_to(want, cover.shape)), "a tile is missing or computed twice"
     assert sorted(vslot_part) == list(range(pl["n_vslots"]))
     for v0, v1, slot in pl["splits"]:
         parts = [vslot_part[v] for v in range(v0, v1)]
         assert len(parts) >= 2 and len({pp[:3] for pp in parts}) == 1
-        assert parts[0][3] == 0 and parts[-1][4] == parts[0][2] + 1
+        assert parts[0][3] == 0 and parts[-1][4] == KQ * (parts[0][2] + 1)
         assert all(a[4] == b[3] for a, b in zip(parts, parts[1:])), "parts of a cut sweep must tile its k range in order"
         assert slot not in slot_sweeps
         slot_sweeps[slot] = [parts[0][:3]]
@@ -348,7 +350,7 @@ def test_variance_work_plan_is_a_partition(cols, nbi, nt, P, order):
     busy = cost[cost > 0]
     ncb_t = pl["ncb"] - pl["nfull"]
     if len(busy) == P and pl["nfull"] == 0:               # every workgroup has work
-        # one list cut at tile granularity: shares within a tile of each other; or two cohorts (whole long sweeps | cut short
+        # one list cut at quarter-tile granularity: shares within a tile of each other (a diagonal tile is not divided); or two cohorts (whole long sweeps | cut short
         # sweeps), balanced by the choice of ONE i-block boundary and only used when that balances to a few per cent
         assert (busy.max() - busy.min() <= 2 * 128 + 72 or (order <= 0 and 2 * ncb_t >= P and busy.max() <= 1.06 * busy.mean())
                 or (order == 1 and busy.max() <= 1.06 * busy.mean()))        # (sweep-major diagnostic order: overheads of many cuts)
@@ -371,10 +373,10 @@ def test_variance_work_plan_cohorts_keep_the_long_sweeps_whole():
             whole = [it for it in items if int(it[7]) < 0]
             part = [it for it in items if int(it[7]) >= 0]
             assert [int(it[2]) for it in whole] == list(range(nbi - 1, s - 1, -1))          # ib = nbi-1 .. s, whole
-            assert all(int(it[3]) == 0 and int(it[4]) == int(it[2]) + 1 for it in whole)
+            assert all(int(it[3]) == 0 and int(it[4]) == 4 * (int(it[2]) + 1) for it in whole)
             # at most one partial product, the LAST tiles of the next shorter sweep (what balances the two cohorts), the
             # same for every block
-            assert len(part) <= 1 and all(int(it[2]) == s - 1 and int(it[3]) >= 1 and int(it[4]) == s for it in part)      # ... up to the diagonal
+            assert len(part) <= 1 and all(int(it[2]) == s - 1 and int(it[3]) >= 4 and int(it[4]) == 4 * s for it in part)  # ... up to the diagonal
             assert [tuple(int(v) for v in it[2:5]) for it in part] == [tuple(int(v) for v in it[2:5]) for it in first[0] if int(it[7]) >= 0]
         rest = pl["items"][ib_[ncb]:]
         assert len(rest) and max(int(it[2]) for it in rest) == s - 1
@@ -467,3 +469,164 @@ def test_hyperparameter_search_driver_sequential_and_concurrent(monkeypatch):
     # every extra handle of a concurrent search is closed again; the owner's handle stays open
     extra_open = [h for h in created if not h.closed]
     assert len(extra_open) == 4          # one owner handle per optimize_hyperparameters call (2 kernels x 2 worker settings)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Plan of the recursive factor + inverse (csrc/gpt_fit_plan.h): host code, replayed here for every padded size
+def _check_fit_plan(NP, leaf, rec_min, fork_min):
+    from gaussian_process_transportation_amd import _lib
+    K = {k: i for i, k in enumerate(_lib.FIT_OP_KINDS)}
+    pl = _lib.debug_fit_plan(NP, leaf, rec_min, fork_min)
+    ops, arena = pl["ops"], pl["arena"]
+    if leaf < 0:
+        assert pl["allocated"] >= arena          # what the fit workspace allocates for the plan the environment selects
+    live = {}                       # name -> (begin, end) of the scratch regions alive at this point of the stream order
+    covered_factor, covered_inverse = [], []
+    forks = 0
+
+    def claim(name, b, size):
+        assert 0 <= b and b + size <= arena, (NP, leaf, name, b, size, arena)
+        for other, (ob, oe) in live.items():
+            assert b + size <= ob or oe <= b, (NP, leaf, name, other)
+        live[name] = (b, b + size)
+
+    for o in ops:
+        kind, side, depth, off, n1, n2, r0, r0s, r1, r1s = (int(v) for v in o)
+        assert 0 <= off and off + n1 + n2 <= NP and n1 % 64 == 0 and n2 % 64 == 0
+        if kind == K["LEAF_FACTOR"]:
+            covered_factor.append((off, off + n1))
+        elif kind == K["LEAF_INVERSE"]:
+            # what trinv_levels really touches: level sz writes (pairs - 1) blocks of sz x sz and m_last x sz of the last pair
+            ext, sz = 0, 64
+            while sz < n1:
+                npairs = (n1 + 2 * sz - 1) // (2 * sz)
+                m_last = n1 - (npairs - 1) * 2 * sz - sz
+                nbp = npairs
+                if m_last <= 0:
+                    nbp, m_last = npairs - 1, sz
+                if nbp > 0:
+                    ext = max(ext, (nbp - 1) * sz * sz + min(m_last, sz) * sz)
+                sz *= 2
+            assert r0s >= ext
+            claim("leaf", r0, r0s); del live["leaf"]
+            covered_inverse.append((off, off + n1))
+        elif kind == K["L21"]:
+            assert r0s == n1 * n2
+            claim(("P", depth), r0, r0s)
+        elif kind == K["COPY_L21"]:
+            assert live[("P", depth)] == (r0, r0 + r0s)
+        elif kind == K["SYRK"]:
+            assert live.pop(("P", depth)) == (r0, r0 + r0s)          # the bounce buffer dies here
+        elif kind == K["T21"]:
+            assert r1s == n1 * n2
+            claim(("T", depth), r1, r1s)
+        elif kind == K["W21"]:
+            assert live.pop(("T", depth)) == (r1, r1 + r1s)
+        elif kind == K["FORK"]:
+            forks += 1
+            assert n1 + n2 >= fork_min > 0 or fork_min <= 0
+        elif kind == K["JOIN"]:
+            forks -= 1
+        assert depth < 16
+    assert not live and forks == 0
+    # the leaves tile the diagonal exactly, in order
+    for cov in (covered_factor, covered_inverse):
+        assert cov[0][0] == 0 and cov[-1][1] == NP and all(cov[i][1] == cov[i + 1][0] for i in range(len(cov) - 1))
+    assert sum(1 for o in ops if o[0] == K["FACTORED"]) == 1
+    return pl
+
+
+def test_fit_plan_regions_stay_inside_the_arena_for_every_size():
+    """Round 3 ended with a GPU memory fault from a scratch layout that assumed a half split.  The
+    layout is now produced by the walk that sizes the arena; this replays it for every padded size up to 16384, four leaf
+    sizes and both recursion thresholds: every region inside the arena, no two live regions overlapping, leaves tiling
+    the diagonal, T21 alive from its product to W21, the bounce buffer from L21 to the SYRK."""
+    n_rec = 0
+    for NP in range(512, 16384 + 1, 512):
+        for leaf in (256, 512, 1024, 2048):
+            for rec_min, fork_min in ((4096, 4096), (0, 1024), (0, 1 << 30)):
+                pl = _check_fit_plan(NP, leaf, rec_min, fork_min)
+                n_rec += pl["recursive"]
+                if pl["recursive"]:
+                    assert pl["arena"] <= 0.60 * NP * NP + 2 * 512 * 512 + 4096      # T stack (1/3) + bounce (1/4) at most
+    assert n_rec > 100
+    for NP in (512, 4096, 4608, 8192, 12288):
+        _check_fit_plan(NP, -1, -1, -1)
+    pl = _check_fit_plan(8192, 1024, 4096, 4096)
+    kinds = [int(o[0]) for o in pl["ops"]]
+    assert kinds.count(0) == 8 and kinds.count(2) == 7 and kinds.count(5) == 3      # 8 leaves, 7 levels, 3 forks (8192, 4096, 4096)
+
+
+class _FakeHandle:
+    """Stands in for _lib.Handle in the CPU test of the device group: records calls, predicts f(x) row by row."""
+    made = []
+
+    def __init__(self, device=0):
+        self.device = device
+        self.calls = []
+        self.replica_of = None
+        _FakeHandle.made.append(self)
+
+    def fit(self, *a, **k):
+        self.calls.append("fit")
+
+    def factor_copy_from(self, src):
+        self.replica_of = src
+
+    def model_info(self):
+        return 1, 0
+
+    def predict_all(self, Xq, mean=False, var=False, J=False, Jvar=False, dvar=False):
+        import threading
+        self.calls.append(("predict", Xq.shape[0], threading.current_thread().name))
+        if np.any(Xq[:, 0] < -1e6):
+            raise ValueError("poisoned shard")
+        M, D = Xq.shape
+        return {"mean": np.stack([Xq.sum(1), Xq[:, 0]], 1) if mean else None, "var": (Xq ** 2).sum(1) if var else None,
+                "J": np.repeat(Xq[:, None, :], 2, axis=1) if J else None, "Jvar": Xq * 3.0 if Jvar else None,
+                "dvar": (Xq * 5.0).T.copy() if dvar else None}
+
+    def close(self):
+        self.calls.append("close")
+
+    def export(self):
+        return "exported-by-%d" % self.device
+
+
+def test_device_group_shards_rows_over_handles_and_assembles(monkeypatch):
+    """GaussianProcess(devices=[...]): host plumbing of the one-process multi-GPU form — fit on the
+    first handle, one replica copy per further device, contiguous balanced row shards on a thread per device, outputs
+    assembled in row order (dvar along its second axis), small batches left to the first device, errors propagated."""
+    from gaussian_process_transportation_amd import _lib, device_group
+    _FakeHandle.made = []
+    monkeypatch.setattr(_lib, "Handle", _FakeHandle)
+    g = device_group.DeviceGroup([0, 1, 2])
+    h0, h1, h2 = g.handles
+    with pytest.raises(_lib.GptError):
+        g.predict_all(np.zeros((5000, 3)), mean=True)
+    g.fit("X", "Y")
+    assert h0.calls == ["fit"] and h1.replica_of is h0 and h2.replica_of is h0 and h1.calls == []
+    assert g.export() == "exported-by-0"                      # everything but predictions: the first handle
+    rng = np.random.default_rng(0)
+    X = rng.standard_normal((5001, 3))
+    out = g.predict_all(X, mean=True, var=True, J=True, Jvar=True, dvar=True)
+    ref = _FakeHandle(9).predict_all(X, mean=True, var=True, J=True, Jvar=True, dvar=True)
+    for k in ref:
+        assert np.array_equal(out[k], ref[k]), k
+    sizes = [c[1] for h in (h0, h1, h2) for c in h.calls if isinstance(c, tuple)]
+    assert sizes == [1667, 1667, 1667]
+    assert all(c[2].startswith("gpt-dev") for h in (h0, h1, h2) for c in h.calls if isinstance(c, tuple))     # the group's worker threads
+    assert g.predict_all(X, var=True)["mean"] is None
+    small = g.predict_all(X[:100], mean=True)                  # not worth a hand-off: first device alone
+    assert np.array_equal(small["mean"], ref["mean"][:100]) and [c for c in h1.calls if isinstance(c, tuple)][-1][1] == 1667
+    bad = X.copy(); bad[4000, 0] = -1e9
+    with pytest.raises(ValueError, match="poisoned"):
+        g.predict_all(bad, mean=True)
+    g.close()
+    assert h2.calls[-1] == "close"
+    # the class surface: devices= reaches the regressor; one device keeps the plain handle
+    from gaussian_process_transportation_amd import GaussianProcessTransportation
+    t = GaussianProcessTransportation(optimizer=None, devices=[0, 1], verbose=False)
+    assert t.method.delta_map.devices == [0, 1] and t.method.delta_map.device == 0
+    with pytest.raises(ValueError):
+        GaussianProcessTransportation(devices=[])

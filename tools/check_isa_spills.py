@@ -3,7 +3,7 @@ basic block of the hot loop (>= 64 MFMAs, no exp: the reload sweeps) contains sc
 reload there costs more than its own latency: it is a vector-memory operation, so the `s_waitcnt vmcnt` in front of its
 use also drains the A-fragment loads in flight (measured round 2: 24 such reloads appeared in the fp64 kernel when the
 LDS image was indexed with vector-pointer arithmetic instead of element-pointer arithmetic).
-usage: python tools/check_isa_spills.py   (CPU only; hipcc cross-compiles)"""
+usage: python tools/check_isa_spills.py [-DFLAG ...]   (CPU only; hipcc cross-compiles)"""
 import os
 import re
 import subprocess
@@ -13,9 +13,10 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gaussian_process_transportation_amd", "csrc", "gpt_predict.hip")
 with tempfile.TemporaryDirectory() as d:
+    # device side only (-save-temps also runs the host pass over the intermediate files, which hipcc 7.2 rejects for this source)
     subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-value", "-fno-gpu-rdc",
-                    "-save-temps", "-c", SRC, "-o", "p.o"], cwd=d, check=True, capture_output=True)
-    s = open(os.path.join(d, "gpt_predict-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
+                    "--cuda-device-only", "-S", SRC, "-o", "dev.s"] + sys.argv[1:], cwd=d, check=True, capture_output=True)
+    s = open(os.path.join(d, "dev.s")).read()
 bad = 0
 for name in re.findall(r"^(_ZN3gpt5k_varI\w+):", s, flags=re.M):
     i = s.index("\n" + name + ":")
