@@ -83,7 +83,7 @@ inline FitPlan fit_plan(int NP, int leaf = -1, int rec_min = -1, int fork_min = 
     if (pl.leaf < 256) pl.leaf = 256;
     const int rmin = rec_min >= 0 ? rec_min : fit_env_int("GPT_FIT_REC_MIN", 4096);
     pl.fork_min = fork_min >= 0 ? fork_min : fit_env_int("GPT_FIT_FORK_MIN", 4096);
-    pl.recursive = fit_env_int("GPT_FIT_RECURSIVE", 1) != 0 && NP >= rmin && NP > pl.leaf;
+    pl.recursive = fit_env_int("GPT_FIT_RECURSIVE", 0) != 0 && NP >= rmin && NP > pl.leaf;
     size_t top = 0;
     auto push = [&](size_t n) { const size_t o = top; top += (n + 511) / 512 * 512; if (top > pl.arena) pl.arena = top; return o; };
     struct Rec {

@@ -129,6 +129,8 @@ inline VarPlanHost build_var_plan(int64_t ncols, int nbi, int ntask, int P, int 
     std::vector<std::vector<Contribution>> contrib;
     std::vector<std::vector<VarItem>> wg;
     constexpr int TOL = VAR_Q_COST / 2;
+    // diagnostic: GPT_VAR_CUT_TILES=1 cuts at whole tiles (the granularity of rounds 2 and 3) for A/B runs
+    const int gran = [] { const char* e = getenv("GPT_VAR_CUT_TILES"); return (e && atoi(e) != 0) ? VAR_KQ : 1; }();
     // lays `sw` end to end over the workgroups [p_begin, p_begin + Pn) in Pn ranges of equal cost; U = total cost to share
     auto cut_range = [&](const std::vector<Sweep>& sw, const int p_begin, const int Pn, const int64_t U) -> int64_t {
         int p = 0;
@@ -150,6 +152,7 @@ inline VarPlanHost build_var_plan(int64_t ncols, int nbi, int ntask, int P, int 
                     int64_t nt = (room - VAR_SWEEP_OVERHEAD + TOL) / VAR_Q_COST;
                     const int max_take = (kend > diag_lo ? diag_lo : kend - 1) - k;
                     if (nt > max_take) nt = max_take;
+                    nt = nt / gran * gran;
                     if (nt < 1) { ++p; continue; }                       // nothing fits: close this workgroup
                     take = (int)nt;
                 }

@@ -129,11 +129,7 @@ class GaussianProcess:
             from .hyperopt import optimize_hyperparameters
             c, ls, noise, lml = optimize_hyperparameters(self, c, ls, noise)
         if self._handle is None:
-            if self.devices is not None and len(self.devices) > 1:
-                from .device_group import DeviceGroup
-                self._handle = DeviceGroup(self.devices)
-            else:
-                self._handle = _lib.Handle(self.device)
+            self._handle = self._new_handle()
         self._handle.set_dtype(self._dtype)
         self._handle.fit(self.X, self.Y, ls, c, noise, self.alpha, self._ktype)
         self._K_inv = None
@@ -154,6 +150,13 @@ class GaussianProcess:
         if self.verbose:
             print("lenghtscales", fitted.get_params()[_PARAM_LS])
         return self
+
+    def _new_handle(self):
+        """One handle on `device`, or — devices=[a, b, ...] — the group that fits on the first and predicts on all."""
+        if self.devices is not None and len(self.devices) > 1:
+            from .device_group import DeviceGroup
+            return DeviceGroup(self.devices)
+        return _lib.Handle(self.device)
 
     @property
     def K_inv(self):

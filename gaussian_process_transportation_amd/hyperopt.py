@@ -65,7 +65,8 @@ def optimize_hyperparameters(gp, c0, ls0, noise0):
     if gp.optimizer != "fmin_l_bfgs_b" and not callable(gp.optimizer):
         raise ValueError(f"Unknown optimizer {gp.optimizer}.")        # sklearn/_gpr.py:668-669
     if gp._handle is None:
-        gp._handle = _lib.Handle(gp.device)
+        make = getattr(gp, "_new_handle", None)            # (devices=[...]: the group whose first handle runs the search)
+        gp._handle = make() if make is not None else _lib.Handle(gp.device)
     h = gp._handle
     n_ls = int(np.size(ls0))
     free = _free_mask(kernel, n_ls)

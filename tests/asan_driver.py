@@ -66,6 +66,7 @@ h.set_dtype(_lib.GPT_F64)
 # a size the recursive factor + inverse runs at (csrc/gpt_fit_plan.h): the stand-in replays every scratch region of the plan
 # inside the arena the orchestration allocated — with the plan changing under the handle between two fits
 import os
+os.environ["GPT_FIT_RECURSIVE"] = "1"       # (off by default)
 for leaf in ("512", "2048", None):
     if leaf is None:
         os.environ.pop("GPT_FIT_LEAF", None)
@@ -74,6 +75,7 @@ for leaf in ("512", "2048", None):
     Xb = rng.uniform(0, 1, (4200, 3))
     h.fit(Xb, rng.standard_normal((4200, 2)), np.full(3, 0.3), 1.0, 1e-2, 1e-10)
     assert _lib.debug_fit_plan(4608)["recursive"]
+os.environ.pop("GPT_FIT_RECURSIVE")
 h2 = _lib.Handle(0)
 h2.factor_copy_from(h)                      # one-process replica (gpt_factor_copy)
 assert h2.info() == h.info() and h2.model_info() == h.model_info()

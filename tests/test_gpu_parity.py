@@ -1456,3 +1456,125 @@ def test_transport_orientation_on_the_recorded_robot_demo():
         if identity:
             assert np.max(np.abs(Rout - Rin)) < 1e-6
             assert_parity(tr.training_traj, traj, 1e-6, "identity transport leaves the positions")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# round 4
+def test_devices_argument_shards_rows_over_the_handles_of_one_process():
+    """GaussianProcess(devices=[...]) / GaussianProcessTransportation(devices=[...]) (SURVEY 8b's n_devices):
+    fit on the first device, one gpt_factor_copy per further device, predict / derivative / derivative_of_variance shard their
+    rows over a host thread per device.  This pool has one GPU: the same device listed twice is two handles, two streams and a
+    device-to-device copy of the model — everything but the peer link.  Against the single-handle class: mean and Jacobian are
+    per-query contractions (bit-identical); a variance depends on its batch at the last-bit level (the work split depends on M),
+    so the shards are held bit for bit to the single handle predicting the same shard alone, and to 1e-10 to the whole batch."""
+    from sklearn.gaussian_process.kernels import RBF, ConstantKernel, WhiteKernel
+    from gaussian_process_transportation_amd import GaussianProcess, GaussianProcessTransportation
+    from gaussian_process_transportation_amd.device_group import DeviceGroup
+    from gaussian_process_transportation_amd.distributed import shard_range
+    g = load_golden("synthetic_3d_N1024")
+    kern = ConstantKernel(0.1) * RBF([0.1, 0.1, 0.1]) + WhiteKernel(1e-4)
+    one = GaussianProcess(kern, optimizer=None, verbose=False).fit(g["X"], g["Y"])
+    two = GaussianProcess(kern, optimizer=None, verbose=False, devices=[0, 0]).fit(g["X"], g["Y"])
+    assert isinstance(two._handle, DeviceGroup) and len(two._handle.handles) == 2
+    M = 5001
+    Xq = np.random.default_rng(3).uniform(-0.1, 1.1, (M, 3))
+    m1, s1 = one.predict(Xq, return_std=True)
+    m2, s2 = two.predict(Xq, return_std=True)
+    J1, V1 = one.derivative(Xq, return_var=True)
+    J2, V2 = two.derivative(Xq, return_var=True)
+    assert np.array_equal(m1, m2) and np.array_equal(J1, J2)
+    assert_parity(s2, s1, 1e-10, "std, sharded vs whole batch")
+    assert_parity(V2, V1, 1e-10, "Jacobian variance, sharded vs whole batch")
+    assert_parity(two.derivative_of_variance(Xq), one.derivative_of_variance(Xq), 1e-9, "d var, sharded vs whole batch")
+    for r in range(2):
+        a, b = shard_range(M, r, 2)
+        ms, ss = one.predict(Xq[a:b], return_std=True)
+        assert np.array_equal(ms, m2[a:b]) and np.array_equal(ss, s2[a:b]), "a shard must be what one handle predicts for it"
+    # the golden vectors through the sharded class (the reference's own numbers: gaussian_process.py:46-55, 63-102)
+    mg, sg = two.predict(np.tile(g["Xq"], (40, 1)), return_std=True)
+    nq = len(g["Xq"])
+    assert_parity(mg[-nq:], g["mean"], RTOL, "mean (second shard)")
+    assert_parity(sg[:nq], g["std"], RTOL, "std (first shard)")
+    # fit-side state stays with the first handle; the replica refuses what it does not hold
+    assert two.gp.L_.shape == (1024, 1024) and np.isfinite(two.gp.log_marginal_likelihood_value_)
+    assert two.predict(g["Xq"][:50], return_cov=True)[1].shape == (50, 50, 3)
+    from gaussian_process_transportation_amd import _lib
+    with pytest.raises(_lib.GptError):
+        two._handle.handles[1].export(want_alpha=False)
+    # the user-facing class
+    rng = np.random.default_rng(0)
+    src = rng.uniform(0, 1, (300, 3)); tgt = src + 0.05 * np.sin(3 * src)
+    res = []
+    for devs in (None, [0, 0]):
+        tr = GaussianProcessTransportation(kernel_transport=ConstantKernel(0.1) * RBF([0.3]) + WhiteKernel(1e-4), optimizer=None,
+                                           verbose=False, devices=devs)
+        tr.source_distribution, tr.target_distribution = src, tgt
+        tr.training_traj = rng.uniform(0, 1, (2000, 3)); tr.training_delta = rng.standard_normal((2000, 3))
+        tr.fit_transportation()
+        tr.apply_transportation()
+        res.append((tr.training_traj, tr.std, tr.training_delta, tr.var_vel_transported))
+    for a, b, name in zip(res[0], res[1], ("traj", "std", "vel", "var_vel")):
+        assert_parity(b, a, 1e-10, name + " (devices=[0, 0] vs one device)")
+    two._handle.close()
+
+
+@pytest.mark.parametrize("N", [4200, 5300])
+def test_recursive_factor_and_inverse(N, monkeypatch):
+    """The recursive form of the factor + inverse (csrc/gpt_fit_plan.h; off by default: profiles/r04_fit_summary.txt) — L against
+    LAPACK, W L = I, alpha, the pivot of a matrix that stops being positive definite in the LAST leaf, for two leaf sizes (the
+    plan — and the scratch arena it needs — changes under ONE handle between fits), with and without the side stream."""
+    import scipy.linalg
+    from gaussian_process_transportation_amd import _lib
+    from oracle import gp_oracle as orc
+    rng = np.random.default_rng(N)
+    X = rng.uniform(0, 1, (N, 3))
+    Y = np.sin(3 * X[:, :2])
+    ls, c, noise, jit = np.array([0.25, 0.3, 0.2]), 0.7, 1e-3, 1e-10
+    Kref = c * orc.rbf_gram(X / ls) + (noise + jit) * np.eye(N)
+    Lref = np.linalg.cholesky(Kref)
+    aref = scipy.linalg.cho_solve((Lref, True), Y)
+    monkeypatch.setenv("GPT_FIT_RECURSIVE", "1")
+    h = _lib.Handle(0)
+    for leaf, overlap in (("512", "1"), ("2048", "0"), ("1024", "1")):
+        monkeypatch.setenv("GPT_FIT_LEAF", leaf)
+        monkeypatch.setenv("GPT_FIT_OVERLAP", overlap)
+        assert _lib.debug_fit_plan((N + 511) // 512 * 512)["recursive"]
+        if overlap == "0":
+            h.close(); h = _lib.Handle(0)                      # (the side stream is made when a handle first needs it)
+        h.fit(X, Y, ls, c, noise, jit)
+        L, alpha = h.export()
+        assert_parity(L, Lref, 1e-11, f"L_ (leaf {leaf})")
+        assert_parity(alpha, aref, 1e-7, f"alpha_ (leaf {leaf})")
+        W = h.export_inverse_factor()
+        assert np.abs(W @ Lref - np.eye(N)).max() < 1e-9
+    Sigma = 1e-3 * np.eye(N)
+    Sigma[N - 300, N - 300] = -2.0
+    with pytest.raises(np.linalg.LinAlgError) as ei:
+        h.fit_noise_matrix(X, Y, ls, c, Sigma)
+    assert int(str(ei.value).split("pivot")[1].split()[0]) == N - 300 + 1
+    h.close()
+
+
+def test_quarter_tile_cuts_change_no_result_beyond_rounding(monkeypatch):
+    """The tail's work split cuts sweeps at quarter tiles since round 4 (gpt_plan.h); GPT_VAR_CUT_TILES=1 restores whole tiles.
+    Same queries, both splits, the shapes whose whole batch is a tail: variances agree to rounding (the order of the partial
+    products' sum changes), and both agree with the oracle."""
+    from gaussian_process_transportation_amd import _lib
+    from oracle import gp_oracle as orc
+    for N, M in ((1024, 4096), (2500, 4096), (2500, 900)):
+        X, Y, Xq = orc.synthetic_problem(N, M)
+        c, ls, noise, jit = 0.1, np.array([0.1, 0.12, 0.09]), 1e-4, 1e-10
+        outs = []
+        for tiles in ("0", "1"):
+            monkeypatch.setenv("GPT_VAR_CUT_TILES", tiles)
+            h = _lib.Handle(0)                                  # (a handle caches the plan of its last launch shape)
+            h.fit(X, Y, ls, c, noise, jit)
+            outs.append(h.predict_all(Xq, var=True, Jvar=True, dvar=True))
+            h.close()
+        for k in ("var", "Jvar", "dvar"):
+            assert_parity(outs[0][k], outs[1][k], 1e-10, f"{k}: quarter-tile vs tile cuts (N={N}, M={M})")
+        idx = np.arange(0, M, 7)
+        L, a = orc.gpr_fit(X, Y, c, ls, noise, jit)
+        _, var, _, Jvar = orc.posterior_all_fast(Xq[idx], X, L, a, c, ls, noise, want_jvar=True)
+        assert_parity(outs[0]["var"][idx], var, RTOL, "var vs oracle")
+        assert_parity(outs[0]["Jvar"][idx], Jvar, RTOL, "Jvar vs oracle")

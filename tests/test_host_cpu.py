@@ -536,11 +536,12 @@ def _check_fit_plan(NP, leaf, rec_min, fork_min):
     return pl
 
 
-def test_fit_plan_regions_stay_inside_the_arena_for_every_size():
+def test_fit_plan_regions_stay_inside_the_arena_for_every_size(monkeypatch):
     """Round 3 ended with a GPU memory fault from a scratch layout that assumed a half split.  The
     layout is now produced by the walk that sizes the arena; this replays it for every padded size up to 16384, four leaf
     sizes and both recursion thresholds: every region inside the arena, no two live regions overlapping, leaves tiling
     the diagonal, T21 alive from its product to W21, the bounce buffer from L21 to the SYRK."""
+    monkeypatch.setenv("GPT_FIT_RECURSIVE", "1")             # (off by default: profiles/r04_fit_summary.txt)
     n_rec = 0
     for NP in range(512, 16384 + 1, 512):
         for leaf in (256, 512, 1024, 2048):
