@@ -1053,17 +1053,18 @@ int gpt_debug_var_plan(int64_t n_columns, int n_iblocks, int n_tasks, int n_work
     return GPT_OK;
 }
 
-int gpt_debug_fit_plan(int n_padded, int leaf, int rec_min, int fork_min, int64_t* counts, int64_t* ops) {
+int gpt_debug_fit_plan(int n_padded, int panel, int rec_min, int streams, int64_t* counts, int64_t* ops) {
     if (n_padded < 64 || n_padded % 64 != 0 || !counts) return fail(GPT_E_ARG, "gpt_debug_fit_plan: bad argument");
-    const FitPlan pl = fit_plan(n_padded, leaf, rec_min, fork_min);
-    counts[0] = (int64_t)pl.ops.size(); counts[1] = (int64_t)pl.arena; counts[2] = pl.recursive ? 1 : 0; counts[3] = pl.max_depth;
+    const FitPlan pl = fit_plan(n_padded, panel, rec_min, streams);
+    counts[0] = (int64_t)pl.ops.size(); counts[1] = (int64_t)pl.arena; counts[2] = pl.blocked ? 1 : 0; counts[3] = pl.n_events;
     counts[4] = (int64_t)factor_scratch_doubles_of(n_padded);
     if (ops)
         for (size_t i = 0; i < pl.ops.size(); ++i) {
             const FitOp& o = pl.ops[i];
-            int64_t* r = ops + 10 * i;
-            r[0] = o.kind; r[1] = o.side; r[2] = o.depth; r[3] = o.off; r[4] = o.n1; r[5] = o.n2;
-            r[6] = (int64_t)o.r0; r[7] = (int64_t)o.r0_size; r[8] = (int64_t)o.r1; r[9] = (int64_t)o.r1_size;
+            int64_t* r = ops + 16 * i;
+            r[0] = o.kind; r[1] = o.stream; r[2] = o.off; r[3] = o.n1; r[4] = o.n2; r[5] = o.k0; r[6] = o.kw;
+            r[7] = (int64_t)o.r0; r[8] = (int64_t)o.r0_size; r[9] = (int64_t)o.r1; r[10] = (int64_t)o.r1_size;
+            r[11] = o.wait[0]; r[12] = o.wait[1]; r[13] = o.wait[2]; r[14] = o.record; r[15] = 0;
         }
     return GPT_OK;
 }

@@ -81,18 +81,14 @@ void launch_add_lower(hipStream_t s, double* K, const double* S, int N, int NP);
 // raw (N, D) sources on the device -> scaled, padded rows (fp64 workspace image; Xm, may be null: the model's copy in dtype)
 void launch_scale_x(hipStream_t s, const double* X, int N, int NP, int D, const double* inv_ls /* host, MAX_D */, double* Xs64, void* Xm, int dtype);
 void launch_dot(hipStream_t s, const double* a, const double* b, int64_t n, double* out);
-// Streams and events of the overlapped factor + inverse pipeline, owned by a handle: two streams confined to disjoint
-// halves of the CUs (hipExtStreamCreateWithCUMask).  Created on first use; `ok` false = unavailable, everything runs in
-// the caller's stream.
+// Streams and events of the blocked factor + inverse (gpt_fit_plan.h), owned by a handle: `side` and `chain` are confined to
+// disjoint sets of CUs (hipExtStreamCreateWithCUMask).  Created on first use; `ok` false = unavailable, everything runs in
+// the caller's stream in the plan's serial order.
+constexpr int FIT_AUX_EVENTS = 256;
 struct FitAux {
     bool tried = false, ok = false;
-    int chain_eighths = 0;         // CUs of stream `sa` in eighths of the chip (the split the streams were made for)
-    hipStream_t sa = nullptr, sb = nullptr;
-    hipEvent_t e_fork = nullptr, e_a = nullptr, e_b = nullptr;
-    // recursive form (gpt_fit_plan.h): one side stream on most of the CUs for the T21 products, an event pair per depth
-    bool side_tried = false, side_ok = false;
-    hipStream_t side = nullptr;
-    hipEvent_t side_fork[16] = {}, side_join[16] = {};
+    hipStream_t side = nullptr, chain = nullptr;
+    hipEvent_t events[FIT_AUX_EVENTS] = {};
 };
 void fit_aux_release(FitAux& aux);
 size_t factor_scratch_doubles(int NP);        // gpt_fit_plan.h

@@ -817,9 +817,16 @@ static int gemm_tile32_threshold() {
 template <bool BT, bool AT = false>
 static void launch_gemm(hipStream_t s, const GemmArgs& g) {
     const int Mmax = g.nbatch == 1 ? g.M_last : (g.M > g.M_last ? g.M : g.M_last);
-    double tiles = (double)g.nbatch * ((Mmax + 127) / 128) * ((g.N + 127) / 128);
-    if (g.lower_only) tiles *= 0.5;
-    if (4.0 * tiles < gemm_tile32_threshold() && gemm_body() == 0) launch_gemm_ts<BT, AT, 32>(s, g);
+    const int tm = (Mmax + 127) / 128, tn = (g.N + 127) / 128;
+    double tiles = (double)g.nbatch * tm * tn;
+    if (g.lower_only) tiles -= 0.5 * (tn < tm ? tn : tm) * ((tn < tm ? tn : tm) - 1);     // the tiles above the diagonal of the leading square
+    // 32-tiles pay four times the operand traffic per flop of a 64-tile: they are for products whose tiles are SHORT chains (rank
+    // 128/256 updates, the small levels of a leaf's inverse).  With K >= 1024 a 64-tile is 25 us of work and a few hundred of
+    // them fill the chip (the 2048^2 x 2048 products of the blocked form: 238 us on 32-tiles, 36 TFLOP/s, against 163-182 us on
+    // 64-tiles for the same flops: profiles/r04_fit_summary.txt)
+    const int Kmax = g.K > g.K_last ? g.K : g.K_last;
+    const double thr32 = Kmax >= 1024 ? 256.0 : (double)gemm_tile32_threshold();
+    if (4.0 * tiles < thr32 && gemm_body() == 0) launch_gemm_ts<BT, AT, 32>(s, g);
     else if (tiles < gemm_tile_threshold()) launch_gemm_ts<BT, AT, 64>(s, g);
     else launch_gemm_ts<BT, AT, 128>(s, g);
 }
@@ -940,76 +947,38 @@ static void trinv_levels(hipStream_t s, const double* L, double* W, int NP, int 
 }
 
 void fit_aux_release(FitAux& aux) {
-    for (hipEvent_t* e : {&aux.e_fork, &aux.e_a, &aux.e_b}) { if (*e) (void)hipEventDestroy(*e); *e = nullptr; }
-    if (aux.sa) (void)hipStreamDestroy(aux.sa);
-    if (aux.sb) (void)hipStreamDestroy(aux.sb);
-    aux.sa = aux.sb = nullptr;
-    aux.tried = aux.ok = false;
-    for (auto& e : aux.side_fork) { if (e) (void)hipEventDestroy(e); e = nullptr; }
-    for (auto& e : aux.side_join) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+    for (auto& e : aux.events) { if (e) (void)hipEventDestroy(e); e = nullptr; }
     if (aux.side) (void)hipStreamDestroy(aux.side);
-    aux.side = nullptr;
-    aux.side_tried = aux.side_ok = false;
+    if (aux.chain) (void)hipStreamDestroy(aux.chain);
+    aux.side = aux.chain = nullptr;
+    aux.tried = aux.ok = false;
 }
 
-// The side stream of the recursive form: T21 = L21 W11 of a level is needed only by that level's W21, after the whole second
-// half has been factored — it runs beside the second half's launch chains on a stream confined to `eighths`/8 of the CUs (bit i
-// of the mask = CU i, dealt round-robin over the XCDs: every XCD keeps 4 CUs free at 7/8), so that a k_potrf_step of the main
-// stream never queues behind a side GEMM's grid (tools/probes/cumask_probe.hip: two plain streams do make it queue).
-static bool fit_side_init(FitAux& aux) {
-    if (aux.side_tried) return aux.side_ok;
-    aux.side_tried = true;
-    if (fit_env_int("GPT_FIT_OVERLAP", 1) == 0) return false;
+// The streams of the blocked form (gpt_fit_plan.h): `side` on the first `eighths`/8 of the CUs (look-ahead updates and the
+// inverse), `chain` on the others (the leaves' launch chains).  Bit i of a CU mask is CU i in the driver's numbering, dealt
+// round-robin over the XCDs, so both sets span all 8 XCDs (7/8: every XCD keeps 4 CUs for the chain).
+// tools/probes/cumask_probe.hip: a launch chain on one mask and a bulk kernel on the other run side by side without delaying
+// each other, which plain streams do not (a k_potrf_step queues behind a GEMM's grid: 19 -> 68-83 us per step, r04_fit_summary.txt).
+static bool fit_aux_init(FitAux& aux, int n_events) {
+    if (aux.tried) return aux.ok && n_events <= FIT_MAX_EVENTS;
+    aux.tried = true;
+    if (n_events > FIT_MAX_EVENTS) return false;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, current_device()) != hipSuccess) return false;
     const int ncu = prop.multiProcessorCount;
     const int eighths = fit_env_int("GPT_FIT_SIDE_EIGHTHS", 7);
     const int n_side = ncu * eighths / 8;
-    if (eighths >= 8) {
-        if (hipStreamCreateWithFlags(&aux.side, hipStreamNonBlocking) != hipSuccess) { aux.side = nullptr; (void)hipGetLastError(); return false; }
-    } else {
-        if (n_side < 16) return false;
-        const int words = (ncu + 31) / 32;
-        std::vector<uint32_t> m(words, 0);
-        for (int i = 0; i < n_side; ++i) m[i / 32] |= 1u << (i % 32);
-        if (hipExtStreamCreateWithCUMask(&aux.side, words, m.data()) != hipSuccess) { aux.side = nullptr; (void)hipGetLastError(); return false; }
-    }
-    bool ok = true;
-    for (auto& e : aux.side_fork) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
-    for (auto& e : aux.side_join) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
-    aux.side_ok = ok;
-    return ok;
-}
-
-// Two CU-masked streams (hipExtStreamCreateWithCUMask): bits [0, split) and the rest — bit i of the mask is CU i in the
-// driver's numbering, dealt round-robin over the XCDs, so both halves span all 8 XCDs.  tools/probes/cumask_probe.hip: a
-// launch chain on one mask and a bulk kernel on the other run side by side without delaying each other, which two plain
-// streams do not (a short kernel queues behind the bulk kernel's grid).
-// `eighths`: CUs of the factorisation's second half in eighths of the chip — 3 (96 of 256) above NP = 6144, 4 up to it
-// (fit at N = 5000 / 6000: 3.76-3.89 / 5.14-5.29 ms with 96 CUs, 3.67 / 5.02 with 128; N = 7000 and 8192: 96 is best of 64 .. 160;
-// gpurun sessions r3cus, r3cus2).  A handle that changes size class gets new streams.
-static bool fit_aux_init(FitAux& aux, int eighths) {
-    if (aux.tried && (!aux.ok || aux.chain_eighths == eighths)) return aux.ok;
-    if (aux.tried) fit_aux_release(aux);
-    aux.tried = true;
-    aux.chain_eighths = eighths;
-    if (const char* env = getenv("GPT_FIT_OVERLAP")) { if (atoi(env) == 0) return false; }
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, current_device()) != hipSuccess) return false;
-    const int ncu = prop.multiProcessorCount;
-    int split = ncu * eighths / 8;
-    if (const char* e = getenv("GPT_FIT_CHAIN_CUS")) split = atoi(e);
-    if (split < 16 || split > ncu - 16) return false;
+    if (n_side < 16 || ncu - n_side < 8) return false;
     const int words = (ncu + 31) / 32;
-    std::vector<uint32_t> ma(words, 0), mb(words, 0);
-    for (int i = 0; i < ncu; ++i) (i < split ? ma : mb)[i / 32] |= 1u << (i % 32);
-    if (hipExtStreamCreateWithCUMask(&aux.sa, words, ma.data()) != hipSuccess) { aux.sa = nullptr; (void)hipGetLastError(); return false; }
-    if (hipExtStreamCreateWithCUMask(&aux.sb, words, mb.data()) != hipSuccess) {
-        (void)hipStreamDestroy(aux.sa); aux.sa = aux.sb = nullptr; (void)hipGetLastError();
+    std::vector<uint32_t> ms(words, 0), mc(words, 0);
+    for (int i = 0; i < ncu; ++i) (i < n_side ? ms : mc)[i / 32] |= 1u << (i % 32);
+    if (hipExtStreamCreateWithCUMask(&aux.side, words, ms.data()) != hipSuccess) { aux.side = nullptr; (void)hipGetLastError(); return false; }
+    if (hipExtStreamCreateWithCUMask(&aux.chain, words, mc.data()) != hipSuccess) {
+        (void)hipStreamDestroy(aux.side); aux.side = aux.chain = nullptr; (void)hipGetLastError();
         return false;
     }
     bool ok = true;
-    for (hipEvent_t* e : {&aux.e_fork, &aux.e_a, &aux.e_b}) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
+    for (auto& e : aux.events) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
     aux.ok = ok;
     return ok;
 }
@@ -1025,144 +994,74 @@ __global__ __launch_bounds__(256) void k_copy2d(const double* __restrict__ src, 
     }
 }
 
-// Executes the plan of gpt_fit_plan.h (see there for the algebra).
-static void run_fit_plan(const FitPlan& pl, hipStream_t s, double* K, double* W, int NP, int* info, double* scratch, FitAux* aux,
-                         hipEvent_t ev_factored) {
-    bool want_side = false;
-    for (const FitOp& op : pl.ops) want_side = want_side || op.kind == FOP_FORK;
-    const bool side_ok = want_side && aux && fit_side_init(*aux);
-    const int leaf_grp = fit_env_int("GPT_FIT_LEAF_GROUP", 1);
+static_assert(FIT_AUX_EVENTS == FIT_MAX_EVENTS, "event pool of a handle = what a plan may ask for");
+// Executes the plan of gpt_fit_plan.h (see there for the algebra, the streams and the events).
+void launch_factor_inverse(hipStream_t s, double* K, double* W, int NP, int* info, double* scratch, FitAux* aux, hipEvent_t ev_factored) {
+    FitPlan pl = fit_plan(NP);
+    bool multi = false;
+    for (const FitOp& op : pl.ops) multi = multi || op.stream != FS_MAIN;
+    if (multi && !(aux && fit_aux_init(*aux, pl.n_events))) { pl = fit_plan(NP, -1, -1, 0); multi = false; }     // no masked streams: the serial order
+    const int leaf_grp = pl.blocked ? fit_env_int("GPT_FIT_LEAF_GROUP", 1) : 0;
     for (const FitOp& op : pl.ops) {
-        const int off = op.off, n1 = op.n1, n2 = op.n2;
-        hipStream_t st = (op.side && side_ok) ? aux->side : s;
-        double* const K21 = K + (size_t)(off + n1) * NP + off;
-        double* const W11 = W + (size_t)off * NP + off;
+        const int off = op.off, b = op.n1, r = op.n2;
+        hipStream_t st = !multi ? s : (op.stream == FS_SIDE ? aux->side : (op.stream == FS_CHAIN ? aux->chain : s));
+        if (multi)
+            for (int e : op.wait) if (e >= 0) hipStreamWaitEvent(st, aux->events[e], 0);
+        double* const Wpp = W + (size_t)off * NP + off;
         switch (op.kind) {
         case FOP_LEAF_FACTOR:
-            potrf_groups(s, K, W, NP, info, off / NB, (off + n1) / NB, (off + n1) / NB, pl.recursive ? leaf_grp : 0);
-            potrf_finish(s, K, W, NP, off / NB, (off + n1) / NB);
+            potrf_groups(st, K, W, NP, info, off / NB, (off + b) / NB, (off + b) / NB, leaf_grp);
+            potrf_finish(st, K, W, NP, off / NB, (off + b) / NB);
             break;
         case FOP_LEAF_INVERSE:
-            trinv_levels(s, K, W, NP, off, n1, scratch + op.r0);
+            trinv_levels(st, K, W, NP, off, b, scratch + op.r0);
             break;
         case FOP_FACTORED:
-            if (ev_factored) hipEventRecord(ev_factored, s);
+            if (ev_factored) hipEventRecord(ev_factored, st);
             break;
-        case FOP_L21: {
+        case FOP_UPDATE: {
+            GemmArgs c{};
+            c.A = K + (size_t)off * NP + op.k0; c.lda = NP;              // L[off:, k0:k0+kw]
+            c.B = c.A; c.ldb = NP;                                        // its first b rows, used transposed
+            c.C = K + (size_t)off * NP + off; c.ldc = NP;
+            c.M = c.M_last = NP - off; c.N = b; c.K = c.K_last = op.kw; c.nbatch = 1;
+            c.alpha = -1.0; c.beta = 1.0; c.lower_only = 1;
+            launch_gemm<true>(st, c);
+        } break;
+        case FOP_TRSM: {
             GemmArgs a{};
-            a.A = K21; a.lda = NP;                                   // A21 (n2 x n1), updated by every earlier level
-            a.B = W11; a.ldb = NP;                                   // W11 (n1 x n1, lower), used transposed
-            a.C = scratch + op.r0; a.ldc = n1;
-            a.M = a.M_last = n2; a.N = n1; a.K = a.K_last = n1; a.nbatch = 1;
+            a.A = K + (size_t)(off + b) * NP + off; a.lda = NP;           // A21 (r x b), up to date
+            a.B = Wpp; a.ldb = NP;                                        // W_pp (b x b, lower), used transposed
+            a.C = scratch + op.r0; a.ldc = b;
+            a.M = a.M_last = r; a.N = b; a.K = a.K_last = b; a.nbatch = 1;
             a.alpha = 1.0; a.beta = 0.0; a.bt_lower = 1;
-            launch_gemm<true>(s, a);
+            launch_gemm<true>(st, a);
         } break;
         case FOP_COPY_L21: {
-            const long tot = (long)n2 * n1 / 2;
+            const long tot = (long)r * b / 2;
             const unsigned grid = (unsigned)((tot + 255) / 256 < 4096 ? (tot + 255) / 256 : 4096);
-            hipLaunchKernelGGL(k_copy2d, dim3(grid), dim3(256), 0, s, scratch + op.r0, (long)n1, K21, (long)NP, n2, n1);
+            hipLaunchKernelGGL(k_copy2d, dim3(grid), dim3(256), 0, st, scratch + op.r0, (long)b, K + (size_t)(off + b) * NP + off, (long)NP, r, b);
         } break;
-        case FOP_SYRK: {
-            GemmArgs c{};
-            c.A = scratch + op.r0; c.lda = n1;
-            c.B = c.A; c.ldb = n1;
-            c.C = K + (size_t)(off + n1) * NP + off + n1; c.ldc = NP;
-            c.M = c.M_last = n2; c.N = n2; c.K = c.K_last = n1; c.nbatch = 1;
-            c.alpha = -1.0; c.beta = 1.0; c.lower_only = 1;
-            launch_gemm<true>(s, c);
-        } break;
-        case FOP_FORK:
-            if (side_ok) { hipEventRecord(aux->side_fork[op.depth], s); hipStreamWaitEvent(aux->side, aux->side_fork[op.depth], 0); }
-            break;
-        case FOP_T21: {
+        case FOP_T: {
             GemmArgs a{};
-            a.A = K21; a.lda = NP;                                   // L21
-            a.B = W11; a.ldb = NP;                                   // W11 (lower)
-            a.C = scratch + op.r1; a.ldc = n1;
-            a.M = a.M_last = n2; a.N = n1; a.K = a.K_last = n1; a.nbatch = 1;
+            a.A = K + (size_t)off * NP; a.lda = NP;                       // L[off:off+b, 0:off]
+            a.B = W; a.ldb = NP;                                          // W[0:off, 0:off] (lower)
+            a.C = scratch + op.r1; a.ldc = off;
+            a.M = a.M_last = b; a.N = off; a.K = a.K_last = off; a.nbatch = 1;
             a.alpha = 1.0; a.beta = 0.0; a.b_lower = 1;
             launch_gemm<false>(st, a);
         } break;
-        case FOP_JOIN:
-            if (side_ok) { hipEventRecord(aux->side_join[op.depth], aux->side); hipStreamWaitEvent(s, aux->side_join[op.depth], 0); }
-            break;
-        case FOP_W21: {
+        case FOP_WFIN: {
             GemmArgs c{};
-            c.A = W + (size_t)(off + n1) * NP + off + n1; c.lda = NP;   // W22 (n2 x n2, lower)
-            c.B = scratch + op.r1; c.ldb = n1;                          // T21
-            c.C = W + (size_t)(off + n1) * NP + off; c.ldc = NP;        // W21
-            c.M = c.M_last = n2; c.N = n1; c.K = c.K_last = n2; c.nbatch = 1;
+            c.A = Wpp; c.lda = NP;                                        // W_pp (lower)
+            c.B = scratch + op.r1; c.ldb = off;                           // T
+            c.C = W + (size_t)off * NP; c.ldc = NP;                       // W[off:off+b, 0:off]
+            c.M = c.M_last = b; c.N = off; c.K = c.K_last = b; c.nbatch = 1;
             c.alpha = -1.0; c.beta = 0.0; c.a_lower = 1;
-            launch_gemm<false>(s, c);
+            launch_gemm<false>(st, c);
         } break;
         }
-    }
-}
-
-// L = chol(K) in place and W = L^-1.  `ev_factored` (may be null) is recorded in `s` once L is complete.
-//
-// Serial form (NP < 4096, or no masked streams): Cholesky, finish, recursive-doubling inverse, one after the other in `s`.
-// Overlapped form: the second half of the Cholesky is bound by its launch chain (64 steps + thin updates: most CUs idle),
-// while the inverse of the first half and T21 = L21 W11 — 5/8 of the inverse's flops — need nothing but the first half's
-// columns, final by then.  So after the first half: the rest of the Cholesky runs on 3/8 of the CUs, W11 and T21 on the
-// others; afterwards W22 and W21 = -W22 T21 on the whole chip.  Measured (profiles/r02_fit_overlap.log): N = 8192 10.37 ->
-// 9.66 ms; N = 6000 and 12000 unchanged; N = 16384 slower (its second half is GEMM-bound, not chain-bound) — hence the size window.
-void launch_factor_inverse(hipStream_t s, double* K, double* W, int NP, int* info, double* scratch, FitAux* aux, hipEvent_t ev_factored) {
-    {
-        const FitPlan pl = fit_plan(NP);
-        if (pl.recursive) { run_fit_plan(pl, s, K, W, NP, info, scratch, aux, ev_factored); return; }
-    }
-    const int nb = NP / NB;
-    const int gw = potrf_group(NP) * potrf_outer_blocks();
-    int hb = nb / 2 / gw * gw;                                      // split block column, group-aligned.  NOT tunable as is: the scratch
-                                                                    // layout below (T21 in NP^2/4, half-size inverses in NP^2/16) assumes h <= NP/2 <= r + gw*NB
-    const size_t r_split = (size_t)NP - (size_t)hb * NB;            // rows of the second half
-    const bool fits = r_split * r_split / 4 <= (size_t)NP * NP / 16 + 4096;      // its inverse's scratch (a split off the half, e.g. GPT_POTRF_GROUP=4: serial form)
-    const bool overlap = NP > 4096 && NP <= 12288 && hb >= gw && fits && aux && fit_aux_init(*aux, NP <= 6144 ? 4 : 3);
-    if (!overlap) {
-        potrf_groups(s, K, W, NP, info, 0, nb, nb);
-        potrf_finish(s, K, W, NP, 0, nb);
-        if (ev_factored) hipEventRecord(ev_factored, s);
-        trinv_levels(s, K, W, NP, 0, NP, scratch);
-        return;
-    }
-    const int h = hb * NB, r = NP - h;
-    double* T21 = scratch;                                          // r x h, row-major
-    double* inner = scratch + (size_t)NP * NP / 4;                  // scratch of the half-size inverses
-    potrf_groups(s, K, W, NP, info, 0, hb, nb);                     // columns [0, h) final, A22 carries their update
-    hipEventRecord(aux->e_fork, s);
-    hipStreamWaitEvent(aux->sa, aux->e_fork, 0);
-    hipStreamWaitEvent(aux->sb, aux->e_fork, 0);
-    // stream a: the rest of the factorisation
-    potrf_groups(aux->sa, K, W, NP, info, hb, nb, nb);
-    potrf_finish(aux->sa, K, W, NP, hb, nb);
-    hipEventRecord(aux->e_a, aux->sa);
-    // stream b: W11 = L11^-1, T21 = L21 W11
-    potrf_finish(aux->sb, K, W, NP, 0, hb);
-    trinv_levels(aux->sb, K, W, NP, 0, h, inner);
-    {
-        GemmArgs a{};
-        a.A = K + (size_t)h * NP; a.lda = NP;                       // L21 (r x h)
-        a.B = W; a.ldb = NP;                                        // W11 (h x h, lower)
-        a.C = T21; a.ldc = h;
-        a.M = a.M_last = r; a.N = h; a.K = a.K_last = h; a.nbatch = 1;
-        a.alpha = 1.0; a.beta = 0.0; a.b_lower = 1;
-        launch_gemm<false>(aux->sb, a);
-    }
-    hipEventRecord(aux->e_b, aux->sb);
-    hipStreamWaitEvent(s, aux->e_a, 0);
-    if (ev_factored) hipEventRecord(ev_factored, s);
-    hipStreamWaitEvent(s, aux->e_b, 0);
-    // whole chip again: W22 = L22^-1, W21 = -W22 T21
-    trinv_levels(s, K, W, NP, h, r, inner);
-    {
-        GemmArgs c{};
-        c.A = W + (size_t)h * NP + h; c.lda = NP;                   // W22 (r x r, lower)
-        c.B = T21; c.ldb = h;
-        c.C = W + (size_t)h * NP; c.ldc = NP;                       // W21
-        c.M = c.M_last = r; c.N = h; c.K = c.K_last = r; c.nbatch = 1;
-        c.alpha = -1.0; c.beta = 0.0; c.a_lower = 1;
-        launch_gemm<false>(s, c);
+        if (multi && op.record >= 0) hipEventRecord(aux->events[op.record], st);
     }
 }
 

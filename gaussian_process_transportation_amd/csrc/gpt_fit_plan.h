@@ -1,21 +1,26 @@
-// Plan of the recursive factor + inverse (host-only C++, no HIP: gpt_fit.hip executes it, the CPU sanitizer build's
-// stand-in replays its memory regions, tests/test_host_cpu.py checks them through gpt_debug_fit_plan).
+// Plan of the factor + inverse for large models (host-only C++, no HIP: gpt_fit.hip executes it, the CPU sanitizer build's
+// stand-in replays its memory regions, tests/test_host_cpu.py checks regions AND ordering through gpt_debug_fit_plan).
 //
-// L = chol(A) in place and W = L^-1 for the diagonal block [off, off + n) of an NP x NP matrix:
-//   n <= leaf :  the right-looking blocked factorisation (k_potrf_step chain + rank-128/256 updates confined to the block),
-//                then the block's triangular inverse by recursive doubling                      (LEAF_FACTOR, LEAF_INVERSE)
-//   otherwise :  split n = n1 + n2;   (L11, W11) = rec(A11)
-//                L21 = A21 W11^T                       one GEMM, K = n1 (triangular)           (L21 -> bounce buffer, COPY_L21)
-//                A22 -= L21 L21^T                      one SYRK, K = n1                        (SYRK)
-//                T21 = L21 W11                         side branch: only needed by W21         (FORK, T21 on the side stream)
-//                (L22, W22) = rec(A22)
-//                W21 = -W22 T21                        one GEMM, K = n2 (triangular)           (JOIN, W21)
-// so that three quarters of the 2 N^3 / 3 flops run in products with K = N/2 and nine tenths with K >= 512 — where the fp64 tile
-// GEMM reaches its deep-K rate — instead of in rank-128/256 updates (sklearn/_gpr.py:346-364's cholesky + the explicit inverse of
-// models/gaussian_process.py:42-43 are one LAPACK call each on the CPU; this is their blocked restatement for the GPU).
-// Every scratch region is taken from ONE arena by a stack allocator HERE, sized by the same walk that assigns the
-// offsets: factor_scratch_doubles(NP) = fit_plan(NP).arena — the layout cannot disagree with the size (round 3's fault was
-// a region sized for n/2 used with a split off the half).
+// L = chol(A) in place (sklearn/_gpr.py:346-364's cholesky) and W = L^-1 (the factor of models/gaussian_process.py:42-43's
+// explicit K^-1) are one LAPACK call each on the CPU.  Here, for NP >= rec_min: a LEFT-LOOKING blocked form with panels of
+// `panel` columns (1024) and look-ahead, laid out so that
+//   * every O(N^3) flop sits in a product with K >= panel — where the fp64 tile GEMM reaches its deep-K rate (60 TFLOP/s against
+//     37-54 in the rank-128/256 trailing updates of the right-looking form: profiles/r03_fit_gemm_study.txt, r04_fit_summary.txt);
+//   * the launch chain of the factorisation — 128 k_potrf_step launches at N = 8192, 2.4 ms that nothing can shorten — has the bulk
+//     of the update flops and the WHOLE inverse running beside it instead of behind it.
+// Panel p = columns [o, o + b), r = NP - o - b rows below it:
+//   UPD_BULK(p)  A[o:, o:o+b] -= L[o:, 0:o'] L[o:o+b, 0:o']^T     o' = start of panel p-1: the panels final since TRSM(p-2)   side
+//   UPD_LAST(p)  A[o:, o:o+b] -= L[o:, o':o] L[o:o+b, o':o]^T     panel p-1 alone (K = b), the only update on the chain      main
+//   LEAF(p)      right-looking factorisation of the b x b diagonal block (k_potrf_step chain) + its inverse W_pp               chain
+//   TRSM(p)      L[o+b:, o:o+b] = A[o+b:, o:o+b] W_pp^T            (bounce buffer + copy back)                                 main
+//   T(p)         T = L[o:o+b, 0:o] W[0:o, 0:o]                     needs row p of L (TRSM(p-1)) and W rows < p                 side
+//   WFIN(p)      W[o:o+b, 0:o] = -W_pp T                           needs LEAF(p)                                               side
+// Three streams: `main` (all CUs), `side` (7/8 of the CUs: look-ahead updates and the inverse), `chain` (the other 1/8: the
+// leaves, so that a k_potrf_step never queues behind a side GEMM's grid — measured: 19 -> 68-83 us per step when it does).
+// Cross-stream order is by events; every op lists the events it waits for and the one it records.  The checker in
+// tests/test_host_cpu.py rebuilds the happens-before relation from (stream order + events) and asserts it covers every pair
+// of ops that touch overlapping memory, so a missing wait is a CPU test failure, not a GPU race.
+// Every scratch region comes from ONE arena sized by the same walk that assigns the offsets (factor_scratch_doubles).
 #pragma once
 #include <cstddef>
 #include <cstdint>
@@ -27,29 +32,32 @@ namespace gpt {
 enum FitOpKind {
     FOP_LEAF_FACTOR = 0,   // block columns [off, off + n1) of the diagonal block, rows < off + n1
     FOP_LEAF_INVERSE = 1,  // W[off.., off..] (n1 x n1) from the 64-blocks' inverses; scratch region r0
-    FOP_L21 = 2,           // r0 (n2 x n1, compact) = A21 W11^T
-    FOP_COPY_L21 = 3,      // K21 = r0
-    FOP_SYRK = 4,          // A22 -= r0 r0^T (lower)
-    FOP_FORK = 5,          // side stream waits for everything the main stream has issued (event pair `depth`)
-    FOP_T21 = 6,           // r1 (n2 x n1, compact) = K21 W11; on the side stream when side != 0
-    FOP_JOIN = 7,          // main stream waits for the side stream
-    FOP_W21 = 8,           // W21 = -W22 r1
-    FOP_FACTORED = 9,      // L is complete here (the caller's event)
+    FOP_UPDATE = 2,        // A[off:, off:off+n1] -= L[off:, k0:k0+kw] L[off:off+n1, k0:k0+kw]^T   (rows off .. NP)
+    FOP_TRSM = 3,          // r0 (n2 x n1, compact) = A[off+n1:, off:off+n1] W_pp^T
+    FOP_COPY_L21 = 4,      // L[off+n1:, off:off+n1] = r0
+    FOP_T = 5,             // r1 (n1 x off, compact) = L[off:off+n1, 0:off] W[0:off, 0:off]
+    FOP_WFIN = 6,          // W[off:off+n1, 0:off] = -W_pp r1
+    FOP_FACTORED = 7,      // L is complete here (the caller's event)
 };
+enum { FS_MAIN = 0, FS_SIDE = 1, FS_CHAIN = 2 };
+constexpr int FIT_MAX_EVENTS = 256;
 
 struct FitOp {
-    int kind, side, depth;
-    int off, n1, n2;           // block [off, off + n1 + n2): first part n1, second part n2 (leaf ops: n2 = 0)
-    size_t r0, r0_size;        // arena region (doubles)
+    int kind, stream;
+    int off, n1, n2;           // panel [off, off + n1), n2 rows below it
+    int k0, kw;                // FOP_UPDATE: source columns [k0, k0 + kw)
+    size_t r0, r0_size;        // arena regions (doubles)
     size_t r1, r1_size;
+    int wait[3];               // event ids this op's stream waits for before it (-1: none)
+    int record;                // event id recorded in this op's stream after it (-1: none)
 };
 
 struct FitPlan {
-    int NP = 0, leaf = 0, align = 256, fork_min = 0;
-    bool recursive = false;
+    int NP = 0, panel = 0;
+    bool blocked = false;      // false: the whole matrix is one leaf (the right-looking form + recursive-doubling inverse)
     std::vector<FitOp> ops;
     size_t arena = 0;          // doubles
-    int max_depth = 0;
+    int n_events = 0;
 };
 
 // extent (doubles) of the scratch the recursive-doubling inverse of an n x n block touches (gpt_fit.hip trinv_levels:
@@ -75,64 +83,129 @@ inline int fit_env_int(const char* name, int dflt) {
     return e ? atoi(e) : dflt;
 }
 
-// leaf / rec_min / fork_min < 0: from the environment (GPT_FIT_LEAF, GPT_FIT_REC_MIN, GPT_FIT_FORK_MIN) or the defaults
-inline FitPlan fit_plan(int NP, int leaf = -1, int rec_min = -1, int fork_min = -1) {
+// panel / rec_min < 0: from the environment (GPT_FIT_PANEL, GPT_FIT_REC_MIN) or the defaults.  side: 0 = everything in the
+// main stream (no look-ahead: the serial form of the same algebra), 1 = three streams; < 0: GPT_FIT_OVERLAP or 1.
+inline FitPlan fit_plan(int NP, int panel = -1, int rec_min = -1, int side = -1) {
     FitPlan pl;
     pl.NP = NP;
-    pl.leaf = leaf > 0 ? leaf : fit_env_int("GPT_FIT_LEAF", 1024);
-    if (pl.leaf < 256) pl.leaf = 256;
+    pl.panel = panel > 0 ? panel : fit_env_int("GPT_FIT_PANEL", 1024);
+    pl.panel = (pl.panel + 255) / 256 * 256;
     const int rmin = rec_min >= 0 ? rec_min : fit_env_int("GPT_FIT_REC_MIN", 4096);
-    pl.fork_min = fork_min >= 0 ? fork_min : fit_env_int("GPT_FIT_FORK_MIN", 4096);
-    pl.recursive = fit_env_int("GPT_FIT_RECURSIVE", 0) != 0 && NP >= rmin && NP > pl.leaf;
-    size_t top = 0;
-    auto push = [&](size_t n) { const size_t o = top; top += (n + 511) / 512 * 512; if (top > pl.arena) pl.arena = top; return o; };
-    struct Rec {
-        FitPlan& pl; size_t& top; decltype(push)& push_;
-        void leaf_ops(int off, int n, int depth) {
-            pl.ops.push_back(FitOp{FOP_LEAF_FACTOR, 0, depth, off, n, 0, 0, 0, 0, 0});
-            const size_t mark = top;
-            const size_t ext = trinv_extent(n);
-            const size_t r = push_(ext);
-            pl.ops.push_back(FitOp{FOP_LEAF_INVERSE, 0, depth, off, n, 0, r, ext, 0, 0});
-            top = mark;
+    const bool streams = (side >= 0 ? side : fit_env_int("GPT_FIT_OVERLAP", 1)) != 0;
+    pl.blocked = fit_env_int("GPT_FIT_BLOCKED", 1) != 0 && NP >= rmin && NP > pl.panel;
+    auto op = [](int kind, int stream, int off, int n1, int n2) {
+        FitOp o{};
+        o.kind = kind; o.stream = stream; o.off = off; o.n1 = n1; o.n2 = n2;
+        o.wait[0] = o.wait[1] = o.wait[2] = -1; o.record = -1;
+        return o;
+    };
+    auto al = [](size_t n) { return (n + 511) / 512 * 512; };
+    if (!pl.blocked) {
+        pl.ops.push_back(op(FOP_LEAF_FACTOR, FS_MAIN, 0, NP, 0));
+        pl.ops.push_back(op(FOP_FACTORED, FS_MAIN, 0, 0, 0));
+        FitOp inv = op(FOP_LEAF_INVERSE, FS_MAIN, 0, NP, 0);
+        inv.r0 = 0; inv.r0_size = trinv_extent(NP);
+        pl.ops.push_back(inv);
+        pl.arena = al(inv.r0_size) + 4096;
+        return pl;
+    }
+    // panels: P equal widths, multiples of 256
+    const int P = (NP + pl.panel - 1) / pl.panel;
+    std::vector<int> o(P + 1, 0);
+    {
+        const int wdt = ((NP + P - 1) / P + 255) / 256 * 256;
+        for (int p = 1; p <= P; ++p) o[p] = (o[p - 1] + wdt < NP) ? o[p - 1] + wdt : NP;
+        o[P] = NP;
+    }
+    // arena: [leaf inverse scratch | TRSM bounce | T]   (each used by one stream at a time; see the op list)
+    size_t leaf_scr = 0, bounce = 0, tbuf = 0;
+    for (int p = 0; p < P; ++p) {
+        const int b = o[p + 1] - o[p], r = NP - o[p + 1];
+        if (trinv_extent(b) > leaf_scr) leaf_scr = trinv_extent(b);
+        if ((size_t)r * b > bounce) bounce = (size_t)r * b;
+        if ((size_t)b * o[p] > tbuf) tbuf = (size_t)b * o[p];
+    }
+    const size_t off_leaf = 0, off_bounce = al(leaf_scr), off_t = off_bounce + al(bounce);
+    pl.arena = off_t + al(tbuf) + 4096;
+    int nev = 0;
+    auto new_event = [&]() { return nev++; };
+    const int S_SIDE = streams ? FS_SIDE : FS_MAIN, S_CHAIN = streams ? FS_CHAIN : FS_MAIN;
+    std::vector<int> ev_trsm(P, -1), ev_leaf(P, -1), ev_bulk(P + 1, -1), ev_wfin(P, -1);
+    int ev_t_prev = -1;                      // the T buffer: T(p) must not overwrite what WFIN(p-1) still reads (same stream: ordered)
+    for (int p = 0; p < P; ++p) {
+        const int off = o[p], b = o[p + 1] - o[p], r = NP - o[p + 1];
+        // ---- main: the update by panel p-1 (after the look-ahead part by the earlier panels has landed)
+        if (p >= 1) {
+            FitOp u = op(FOP_UPDATE, FS_MAIN, off, b, r);
+            u.k0 = o[p - 1]; u.kw = o[p] - o[p - 1];
+            u.wait[0] = ev_bulk[p];                                  // (-1 for p == 1: no earlier panels)
+            pl.ops.push_back(u);
         }
-        void run(int off, int n, int depth) {
-            if (depth > pl.max_depth) pl.max_depth = depth;
-            if (!pl.recursive || n <= pl.leaf) { leaf_ops(off, n, depth); return; }
-            int n1 = (n / 2 + pl.align - 1) / pl.align * pl.align;
-            if (n1 >= n) n1 = n - pl.align;
-            const int n2 = n - n1;
-            run(off, n1, depth + 1);
-            const size_t mark = top;
-            const size_t sz = (size_t)n2 * n1;
-            const size_t t = push_(sz);         // T21: lives until W21
-            const size_t p = push_(sz);         // bounce buffer of L21: dead after the SYRK
-            const int side = n >= pl.fork_min ? 1 : 0;
-            pl.ops.push_back(FitOp{FOP_L21, 0, depth, off, n1, n2, p, sz, 0, 0});
-            pl.ops.push_back(FitOp{FOP_COPY_L21, 0, depth, off, n1, n2, p, sz, 0, 0});
-            if (side) pl.ops.push_back(FitOp{FOP_FORK, 1, depth, off, n1, n2, 0, 0, 0, 0});
-            pl.ops.push_back(FitOp{FOP_T21, side, depth, off, n1, n2, 0, 0, t, sz});
-            pl.ops.push_back(FitOp{FOP_SYRK, 0, depth, off, n1, n2, p, sz, 0, 0});
-            top = t + (sz + 511) / 512 * 512;   // the bounce buffer is free again
-            run(off + n1, n2, depth + 1);
-            if (side) pl.ops.push_back(FitOp{FOP_JOIN, 1, depth, off, n1, n2, 0, 0, 0, 0});
-            pl.ops.push_back(FitOp{FOP_W21, 0, depth, off, n1, n2, 0, 0, t, sz});
-            top = mark;
+        // ---- chain: the leaf
+        {
+            FitOp lf = op(FOP_LEAF_FACTOR, p == 0 ? FS_MAIN : S_CHAIN, off, b, 0);
+            FitOp li = op(FOP_LEAF_INVERSE, lf.stream, off, b, 0);
+            li.r0 = off_leaf; li.r0_size = trinv_extent(b);
+            if (lf.stream != FS_MAIN) {                              // hand-over main -> chain -> main
+                const int e_in = new_event();
+                pl.ops.back().record = e_in;                         // the update just issued in main
+                lf.wait[0] = e_in;
+            }
+            pl.ops.push_back(lf);
+            if (p == P - 1) {
+                FitOp f = op(FOP_FACTORED, lf.stream, 0, 0, 0);
+                pl.ops.push_back(f);
+            }
+            ev_leaf[p] = new_event();
+            li.record = ev_leaf[p];
+            pl.ops.push_back(li);
         }
-    } rec{pl, top, push};
-    rec.run(0, NP, 0);
-    // L is complete after the last leaf has been factored
-    for (size_t i = pl.ops.size(); i-- > 0;)
-        if (pl.ops[i].kind == FOP_LEAF_FACTOR) {
-            pl.ops.insert(pl.ops.begin() + (long)i + 1, FitOp{FOP_FACTORED, 0, 0, 0, 0, 0, 0, 0, 0, 0});
-            break;
+        // ---- main: the rows below the panel
+        if (r > 0) {
+            FitOp t = op(FOP_TRSM, FS_MAIN, off, b, r);
+            t.r0 = off_bounce; t.r0_size = (size_t)r * b;
+            t.wait[0] = ev_leaf[p];
+            pl.ops.push_back(t);
+            FitOp c = op(FOP_COPY_L21, FS_MAIN, off, b, r);
+            c.r0 = off_bounce; c.r0_size = (size_t)r * b;
+            ev_trsm[p] = new_event();
+            c.record = ev_trsm[p];
+            pl.ops.push_back(c);
         }
-    pl.arena += 4096;
+        // ---- side: the inverse's block row p (its small last product), then the look-ahead update of panel p+1 by the panels
+        //      < p, then the big product of block row p+1 — in that order: the update is what the chain will wait for
+        if (p >= 1) {
+            FitOp w = op(FOP_WFIN, S_SIDE, off, b, 0);
+            w.r1 = off_t; w.r1_size = (size_t)b * off;
+            w.wait[0] = ev_leaf[p];                                  // W_pp; T(p) precedes it in the same stream
+            if (p == P - 1) { w.stream = FS_MAIN; w.wait[1] = ev_t_prev; }       // the tail of the whole thing: in the caller's stream
+            pl.ops.push_back(w);
+        }
+        if (p + 1 < P && p >= 1) {
+            const int q = p + 1;                                     // panel q gets the panels < p now (final since TRSM(p-1))
+            FitOp u = op(FOP_UPDATE, S_SIDE, o[q], o[q + 1] - o[q], NP - o[q + 1]);
+            u.k0 = 0; u.kw = o[p];
+            u.wait[0] = ev_trsm[p - 1];
+            ev_bulk[q] = new_event();
+            u.record = ev_bulk[q];
+            pl.ops.push_back(u);
+        }
+        if (p + 1 < P) {
+            const int q = p + 1;                                     // T(q) = L[q, 0:o_q] W[0:o_q, 0:o_q]: row q of L is final after TRSM(p)
+            FitOp t = op(FOP_T, S_SIDE, o[q], o[q + 1] - o[q], 0);
+            t.r1 = off_t; t.r1_size = (size_t)(o[q + 1] - o[q]) * o[q];
+            t.wait[0] = ev_trsm[p];                                  // (W rows < q: WFIN(<= p) precede in the same stream; WFIN(p) above)
+            ev_t_prev = new_event();
+            t.record = ev_t_prev;
+            pl.ops.push_back(t);
+        }
+    }
+    pl.n_events = nev;
     return pl;
 }
 
 // Scratch of launch_factor_inverse in doubles: the arena of the plan this size runs with, and never less than what the
-// non-recursive forms use (T of the whole-matrix inverse NP^2/4; the overlapped form's half-size inverses NP^2/16 more).
+// one-leaf form of any size uses (T of the whole-matrix inverse, NP^2/4).
 inline size_t factor_scratch_doubles_of(int NP) {
     const size_t legacy = (size_t)NP * NP / 4 + (size_t)NP * NP / 16 + 4096;
     const size_t planned = fit_plan(NP).arena;

@@ -30,12 +30,10 @@ void launch_dot(hipStream_t, const double* a, const double* b, int64_t n, double
 void launch_add_lower(hipStream_t, double* K, const double* S, int N, int NP) { touch_r(S, (size_t)N * N * 8); touch_w(K, (size_t)NP * NP * 8); }
 void fit_aux_release(FitAux&) {}
 size_t factor_scratch_doubles(int NP) { return factor_scratch_doubles_of(NP); }
-// replays the plan's scratch regions (gpt_fit_plan.h) — and the non-recursive forms' whole-matrix inverse — inside the buffer
-// the orchestration allocated with factor_scratch_doubles
+// replays the plan's scratch regions (gpt_fit_plan.h) inside the buffer the orchestration allocated with factor_scratch_doubles
 void launch_factor_inverse(hipStream_t, double* K, double* W, int NP, int* info, double* scratch, FitAux*, hipEvent_t) {
     touch_w(K, (size_t)NP * NP * 8); touch_w(W, (size_t)NP * NP * 8); *info = 0;
     const FitPlan pl = fit_plan(NP);
-    if (!pl.recursive) { touch_w(scratch, ((size_t)NP * NP / 4 + (size_t)NP * NP / 16) * 8); return; }
     for (const FitOp& op : pl.ops) {
         if (op.r0_size) touch_w(scratch + op.r0, op.r0_size * 8);
         if (op.r1_size) touch_w(scratch + op.r1, op.r1_size * 8);

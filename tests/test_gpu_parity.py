@@ -1504,12 +1504,13 @@ def test_devices_argument_shards_rows_over_the_handles_of_one_process():
     # the user-facing class
     rng = np.random.default_rng(0)
     src = rng.uniform(0, 1, (300, 3)); tgt = src + 0.05 * np.sin(3 * src)
+    traj, vel = rng.uniform(0, 1, (2000, 3)), rng.standard_normal((2000, 3))
     res = []
     for devs in (None, [0, 0]):
         tr = GaussianProcessTransportation(kernel_transport=ConstantKernel(0.1) * RBF([0.3]) + WhiteKernel(1e-4), optimizer=None,
                                            verbose=False, devices=devs)
         tr.source_distribution, tr.target_distribution = src, tgt
-        tr.training_traj = rng.uniform(0, 1, (2000, 3)); tr.training_delta = rng.standard_normal((2000, 3))
+        tr.training_traj, tr.training_delta = traj.copy(), vel.copy()
         tr.fit_transportation()
         tr.apply_transportation()
         res.append((tr.training_traj, tr.std, tr.training_delta, tr.var_vel_transported))
@@ -1519,10 +1520,11 @@ def test_devices_argument_shards_rows_over_the_handles_of_one_process():
 
 
 @pytest.mark.parametrize("N", [4200, 5300])
-def test_recursive_factor_and_inverse(N, monkeypatch):
-    """The recursive form of the factor + inverse (csrc/gpt_fit_plan.h; off by default: profiles/r04_fit_summary.txt) — L against
-    LAPACK, W L = I, alpha, the pivot of a matrix that stops being positive definite in the LAST leaf, for two leaf sizes (the
-    plan — and the scratch arena it needs — changes under ONE handle between fits), with and without the side stream."""
+def test_blocked_factor_and_inverse_across_panel_widths(N, monkeypatch):
+    """The blocked form of the factor + inverse (csrc/gpt_fit_plan.h: left-looking panels, look-ahead updates and the inverse on
+    a side stream, leaves on a chain stream) — L against LAPACK, W L = I, alpha, the pivot of a matrix that stops being positive
+    definite in the LAST panel, for three panel widths (the plan — and the scratch arena it needs — changes under ONE handle
+    between fits), with the three streams and in the serial order, and the one-leaf form (GPT_FIT_BLOCKED=0) beside them."""
     import scipy.linalg
     from gaussian_process_transportation_amd import _lib
     from oracle import gp_oracle as orc
@@ -1533,25 +1535,30 @@ def test_recursive_factor_and_inverse(N, monkeypatch):
     Kref = c * orc.rbf_gram(X / ls) + (noise + jit) * np.eye(N)
     Lref = np.linalg.cholesky(Kref)
     aref = scipy.linalg.cho_solve((Lref, True), Y)
-    monkeypatch.setenv("GPT_FIT_RECURSIVE", "1")
+    NP = (N + 511) // 512 * 512
     h = _lib.Handle(0)
-    for leaf, overlap in (("512", "1"), ("2048", "0"), ("1024", "1")):
-        monkeypatch.setenv("GPT_FIT_LEAF", leaf)
+    Ls = []
+    for panel, overlap, blocked in (("512", "1", "1"), ("2048", "0", "1"), ("1024", "1", "1"), ("1024", "1", "0")):
+        monkeypatch.setenv("GPT_FIT_PANEL", panel)
         monkeypatch.setenv("GPT_FIT_OVERLAP", overlap)
-        assert _lib.debug_fit_plan((N + 511) // 512 * 512)["recursive"]
-        if overlap == "0":
-            h.close(); h = _lib.Handle(0)                      # (the side stream is made when a handle first needs it)
+        monkeypatch.setenv("GPT_FIT_BLOCKED", blocked)
+        assert _lib.debug_fit_plan(NP)["blocked"] == (blocked == "1")
         h.fit(X, Y, ls, c, noise, jit)
         L, alpha = h.export()
-        assert_parity(L, Lref, 1e-11, f"L_ (leaf {leaf})")
-        assert_parity(alpha, aref, 1e-7, f"alpha_ (leaf {leaf})")
+        assert_parity(L, Lref, 1e-11, f"L_ (panel {panel}, streams {overlap}, blocked {blocked})")
+        assert_parity(alpha, aref, 1e-7, f"alpha_ (panel {panel})")
         W = h.export_inverse_factor()
         assert np.abs(W @ Lref - np.eye(N)).max() < 1e-9
+        Ls.append(L)
+        h.fit(X, Y, ls, c, noise, jit)                       # streams and events are reused by the next fit
+        assert np.array_equal(h.export()[0], L)
     Sigma = 1e-3 * np.eye(N)
     Sigma[N - 300, N - 300] = -2.0
-    with pytest.raises(np.linalg.LinAlgError) as ei:
-        h.fit_noise_matrix(X, Y, ls, c, Sigma)
-    assert int(str(ei.value).split("pivot")[1].split()[0]) == N - 300 + 1
+    for blocked in ("1", "0"):
+        monkeypatch.setenv("GPT_FIT_BLOCKED", blocked)
+        with pytest.raises(np.linalg.LinAlgError) as ei:
+            h.fit_noise_matrix(X, Y, ls, c, Sigma)
+        assert int(str(ei.value).split("pivot")[1].split()[0]) == N - 300 + 1
     h.close()
 
 

@@ -472,90 +472,141 @@ def test_hyperparameter_search_driver_sequential_and_concurrent(monkeypatch):
 
 
 # ---------------------------------------------------------------------------------------------------------------
-# Plan of the recursive factor + inverse (csrc/gpt_fit_plan.h): host code, replayed here for every padded size
-def _check_fit_plan(NP, leaf, rec_min, fork_min):
+# Plan of the blocked factor + inverse (csrc/gpt_fit_plan.h): host code, replayed here for every padded size
+def _fit_op_accesses(o, NP):
+    """(reads, writes) of one plan op as rectangles (matrix, row0, row1, col0, col1); scratch regions as ('S', a, b, 0, 1)."""
+    from gaussian_process_transportation_amd import _lib
+    f = dict(zip(_lib.FIT_OP_FIELDS, (int(v) for v in o)))
+    kind = _lib.FIT_OP_KINDS[f["kind"]]
+    off, b, r = f["off"], f["n1"], f["n2"]
+    diagK, diagW = ("K", off, off + b, off, off + b), ("W", off, off + b, off, off + b)
+    S0, S1 = ("S", f["r0"], f["r0"] + f["r0_size"], 0, 1), ("S", f["r1"], f["r1"] + f["r1_size"], 0, 1)
+    if kind == "LEAF_FACTOR":
+        return [diagK, diagW], [diagK, diagW]
+    if kind == "LEAF_INVERSE":
+        return [diagK, diagW, S0], [diagW, S0]
+    if kind == "UPDATE":
+        C = ("K", off, NP, off, off + b)
+        return [("K", off, NP, f["k0"], f["k0"] + f["kw"]), C], [C]
+    if kind == "TRSM":
+        return [("K", off + b, NP, off, off + b), diagW], [S0]
+    if kind == "COPY_L21":
+        return [S0], [("K", off + b, NP, off, off + b)]
+    if kind == "T":
+        return [("K", off, off + b, 0, off), ("W", 0, off, 0, off)], [S1]
+    if kind == "WFIN":
+        return [diagW, S1], [("W", off, off + b, 0, off)]
+    return [], []
+
+
+def _overlap(a, b):
+    return a[0] == b[0] and a[1] < b[2] and b[1] < a[2] and a[3] < b[4] and b[3] < a[4]
+
+
+def _check_fit_plan(NP, panel, rec_min, streams):
     from gaussian_process_transportation_amd import _lib
     K = {k: i for i, k in enumerate(_lib.FIT_OP_KINDS)}
-    pl = _lib.debug_fit_plan(NP, leaf, rec_min, fork_min)
+    F = {k: i for i, k in enumerate(_lib.FIT_OP_FIELDS)}
+    pl = _lib.debug_fit_plan(NP, panel, rec_min, streams)
     ops, arena = pl["ops"], pl["arena"]
-    if leaf < 0:
+    n = len(ops)
+    if panel < 0 and rec_min < 0 and streams < 0:
         assert pl["allocated"] >= arena          # what the fit workspace allocates for the plan the environment selects
-    live = {}                       # name -> (begin, end) of the scratch regions alive at this point of the stream order
-    covered_factor, covered_inverse = [], []
-    forks = 0
-
-    def claim(name, b, size):
-        assert 0 <= b and b + size <= arena, (NP, leaf, name, b, size, arena)
-        for other, (ob, oe) in live.items():
-            assert b + size <= ob or oe <= b, (NP, leaf, name, other)
-        live[name] = (b, b + size)
-
+    # ---- regions inside the arena, panels tile the diagonal, updates cover exactly the columns in front of their panel
+    leaves, upd = [], {}
     for o in ops:
-        kind, side, depth, off, n1, n2, r0, r0s, r1, r1s = (int(v) for v in o)
-        assert 0 <= off and off + n1 + n2 <= NP and n1 % 64 == 0 and n2 % 64 == 0
-        if kind == K["LEAF_FACTOR"]:
-            covered_factor.append((off, off + n1))
-        elif kind == K["LEAF_INVERSE"]:
-            # what trinv_levels really touches: level sz writes (pairs - 1) blocks of sz x sz and m_last x sz of the last pair
-            ext, sz = 0, 64
-            while sz < n1:
-                npairs = (n1 + 2 * sz - 1) // (2 * sz)
-                m_last = n1 - (npairs - 1) * 2 * sz - sz
+        for reg in ("r0", "r1"):
+            a, sz = int(o[F[reg]]), int(o[F[reg + "_size"]])
+            assert 0 <= a and a + sz <= arena, (NP, panel, reg)
+        off, b, r = int(o[F["off"]]), int(o[F["n1"]]), int(o[F["n2"]])
+        assert 0 <= off and off + b + r <= NP and b % 64 == 0
+        if int(o[0]) == K["LEAF_FACTOR"]:
+            leaves.append((off, off + b))
+        if int(o[0]) == K["LEAF_INVERSE"]:
+            ext, sz = 0, 64                      # what trinv_levels really touches
+            while sz < b:
+                npairs = (b + 2 * sz - 1) // (2 * sz)
+                m_last = b - (npairs - 1) * 2 * sz - sz
                 nbp = npairs
                 if m_last <= 0:
                     nbp, m_last = npairs - 1, sz
                 if nbp > 0:
                     ext = max(ext, (nbp - 1) * sz * sz + min(m_last, sz) * sz)
                 sz *= 2
-            assert r0s >= ext
-            claim("leaf", r0, r0s); del live["leaf"]
-            covered_inverse.append((off, off + n1))
-        elif kind == K["L21"]:
-            assert r0s == n1 * n2
-            claim(("P", depth), r0, r0s)
-        elif kind == K["COPY_L21"]:
-            assert live[("P", depth)] == (r0, r0 + r0s)
-        elif kind == K["SYRK"]:
-            assert live.pop(("P", depth)) == (r0, r0 + r0s)          # the bounce buffer dies here
-        elif kind == K["T21"]:
-            assert r1s == n1 * n2
-            claim(("T", depth), r1, r1s)
-        elif kind == K["W21"]:
-            assert live.pop(("T", depth)) == (r1, r1 + r1s)
-        elif kind == K["FORK"]:
-            forks += 1
-            assert n1 + n2 >= fork_min > 0 or fork_min <= 0
-        elif kind == K["JOIN"]:
-            forks -= 1
-        assert depth < 16
-    assert not live and forks == 0
-    # the leaves tile the diagonal exactly, in order
-    for cov in (covered_factor, covered_inverse):
-        assert cov[0][0] == 0 and cov[-1][1] == NP and all(cov[i][1] == cov[i + 1][0] for i in range(len(cov) - 1))
-    assert sum(1 for o in ops if o[0] == K["FACTORED"]) == 1
+            assert int(o[F["r0_size"]]) >= ext
+        if int(o[0]) == K["UPDATE"]:
+            assert off + b + r == NP
+            upd.setdefault(off, []).append((int(o[F["k0"]]), int(o[F["k0"]]) + int(o[F["kw"]])))
+        if int(o[0]) == K["TRSM"]:
+            assert int(o[F["r0_size"]]) == b * r and off + b + r == NP
+        if int(o[0]) == K["T"]:
+            assert int(o[F["r1_size"]]) == b * off
+    assert leaves[0][0] == 0 and leaves[-1][1] == NP and all(leaves[i][1] == leaves[i + 1][0] for i in range(len(leaves) - 1))
+    for off, _ in leaves[1:]:
+        ks = sorted(upd[off])
+        assert ks[0][0] == 0 and ks[-1][1] == off and all(ks[i][1] == ks[i + 1][0] for i in range(len(ks) - 1)), "updates must cover [0, off) once"
+    assert sum(1 for o in ops if int(o[0]) == K["FACTORED"]) == 1
+    if not pl["blocked"]:
+        assert len(leaves) == 1
+        return pl
+    assert sum(1 for o in ops if int(o[0]) == K["WFIN"]) == len(leaves) - 1 == sum(1 for o in ops if int(o[0]) == K["T"])
+    # ---- happens-before from (stream order + events) must order every pair of ops that touch overlapping memory
+    hb = np.zeros((n, n), dtype=bool)
+    last_on, recorded = {}, {}
+    for i, o in enumerate(ops):
+        st = int(o[F["stream"]])
+        if st in last_on:
+            hb[last_on[st], i] = True
+        last_on[st] = i
+        for w in ("wait0", "wait1", "wait2"):
+            e = int(o[F[w]])
+            if e >= 0:
+                assert e in recorded, "wait for an event nobody has recorded yet"
+                hb[recorded[e], i] = True
+        e = int(o[F["record"]])
+        if e >= 0:
+            assert e not in recorded and e < pl["n_events"]
+            recorded[e] = i
+    for k in range(n):                           # transitive closure (ops are in issue order: edges go forward)
+        hb[:, :] |= np.outer(hb[:, k], hb[k, :])
+    acc = [_fit_op_accesses(o, NP) for o in ops]
+    for i in range(n):
+        for j in range(i + 1, n):
+            if hb[i, j]:
+                continue
+            ri, wi = acc[i]
+            rj, wj = acc[j]
+            clash = any(_overlap(a, b) for a in wi for b in rj + wj) or any(_overlap(a, b) for a in ri for b in wj)
+            assert not clash, (NP, panel, "unordered ops touch the same memory", _lib.FIT_OP_KINDS[int(ops[i][0])], ops[i].tolist(),
+                               _lib.FIT_OP_KINDS[int(ops[j][0])], ops[j].tolist())
+    # the caller continues in the main stream: its last op must come after everything
+    main = [i for i, o in enumerate(ops) if int(o[F["stream"]]) == 0]
+    assert all(i == main[-1] or hb[i, main[-1]] for i in range(n)), "work left unjoined when launch_factor_inverse returns"
     return pl
 
 
-def test_fit_plan_regions_stay_inside_the_arena_for_every_size(monkeypatch):
-    """Round 3 ended with a GPU memory fault from a scratch layout that assumed a half split.  The
-    layout is now produced by the walk that sizes the arena; this replays it for every padded size up to 16384, four leaf
-    sizes and both recursion thresholds: every region inside the arena, no two live regions overlapping, leaves tiling
-    the diagonal, T21 alive from its product to W21, the bounce buffer from L21 to the SYRK."""
-    monkeypatch.setenv("GPT_FIT_RECURSIVE", "1")             # (off by default: profiles/r04_fit_summary.txt)
-    n_rec = 0
+def test_fit_plan_regions_and_ordering_for_every_size():
+    """Round 3 ended with a GPU memory fault from a scratch layout that assumed a half split; that code is
+    gone.  The blocked form's layout is produced by the walk that sizes the arena, and its cross-stream order by explicit
+    events: this replays both for every padded size up to 16384 and four panel widths — every region inside the arena, the
+    panels tiling the diagonal, the updates covering the columns in front of each panel exactly once, and the happens-before
+    relation of (stream order + events) ordering EVERY pair of operations that touch overlapping memory (K, W or scratch), in the
+    three-stream form and in the serial one; nothing left unjoined at the end."""
+    n_blocked = 0
     for NP in range(512, 16384 + 1, 512):
-        for leaf in (256, 512, 1024, 2048):
-            for rec_min, fork_min in ((4096, 4096), (0, 1024), (0, 1 << 30)):
-                pl = _check_fit_plan(NP, leaf, rec_min, fork_min)
-                n_rec += pl["recursive"]
-                if pl["recursive"]:
-                    assert pl["arena"] <= 0.60 * NP * NP + 2 * 512 * 512 + 4096      # T stack (1/3) + bounce (1/4) at most
-    assert n_rec > 100
+        for panel in (512, 1024, 1536, 2048):
+            for rec_min, streams in ((4096, 1), (0, 1), (0, 0)):
+                if NP > 8192 and (panel == 512 or rec_min == 0):
+                    continue                     # (keeps the closure small; the large sizes run with the shipped thresholds)
+                n_blocked += _check_fit_plan(NP, panel, rec_min, streams)["blocked"]
+    assert n_blocked > 100
     for NP in (512, 4096, 4608, 8192, 12288):
         _check_fit_plan(NP, -1, -1, -1)
-    pl = _check_fit_plan(8192, 1024, 4096, 4096)
+    pl = _check_fit_plan(8192, 1024, 4096, 1)
     kinds = [int(o[0]) for o in pl["ops"]]
-    assert kinds.count(0) == 8 and kinds.count(2) == 7 and kinds.count(5) == 3      # 8 leaves, 7 levels, 3 forks (8192, 4096, 4096)
+    assert kinds.count(0) == 8 and kinds.count(2) == 7 + 6 and kinds.count(3) == 7        # 8 leaves; 7 last + 6 look-ahead updates; 7 TRSMs
+    streams = {int(o[1]) for o in pl["ops"]}
+    assert streams == {0, 1, 2} and {int(o[1]) for o in _check_fit_plan(8192, 1024, 4096, 0)["ops"]} == {0}
 
 
 class _FakeHandle:
