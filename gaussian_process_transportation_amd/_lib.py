@@ -170,19 +170,21 @@ def debug_var_plan(n_columns, n_iblocks, n_tasks, n_workgroups, order=-1):
             "fin": fin[:counts[6]], "splits": splits[:counts[1]]}
 
 
-FIT_OP_KINDS = ("LEAF_FACTOR", "LEAF_INVERSE", "UPDATE", "TRSM", "COPY_L21", "T", "WFIN", "FACTORED")
-FIT_OP_FIELDS = ("kind", "stream", "off", "n1", "n2", "k0", "kw", "r0", "r0_size", "r1", "r1_size", "wait0", "wait1", "wait2", "record")
+FIT_OP_KINDS = ("POTRF", "FINISH", "TRINV", "UPDATE", "TRSM", "COPY_L21", "T", "WFIN", "FACTORED")
+FIT_OP_FIELDS = ("kind", "stream", "off", "n1", "n2", "k0", "kw", "row_end", "grp", "r0", "r0_size", "r1", "r1_size", "wait0", "wait1",
+                 "wait2", "record")
 
 
-def debug_fit_plan(n_padded, panel=-1, rec_min=-1, streams=-1):
-    """The plan of the blocked factor + inverse (csrc/gpt_fit_plan.h) for a padded size; host code, no GPU.
+def debug_fit_plan(n_padded, form=-1, panel=-1, streams=-1):
+    """The plan of the factor + inverse (csrc/gpt_fit_plan.h) for a padded size; host code, no GPU.
     ops: one row per operation, columns FIT_OP_FIELDS (regions in doubles inside the arena; events by id, -1 = none)."""
     lib = load()
-    counts = (_i64 * 5)()
-    check(lib.gpt_debug_fit_plan(n_padded, panel, rec_min, streams, counts, None))
-    ops = np.zeros((max(counts[0], 1), 16), dtype=np.int64)
-    check(lib.gpt_debug_fit_plan(n_padded, panel, rec_min, streams, counts, ops.ctypes.data_as(C.POINTER(_i64))))
-    return {"arena": counts[1], "blocked": bool(counts[2]), "n_events": counts[3], "allocated": counts[4], "ops": ops[:counts[0], :15]}
+    counts = (_i64 * 6)()
+    check(lib.gpt_debug_fit_plan(n_padded, form, panel, streams, counts, None))
+    ops = np.zeros((max(counts[0], 1), 18), dtype=np.int64)
+    check(lib.gpt_debug_fit_plan(n_padded, form, panel, streams, counts, ops.ctypes.data_as(C.POINTER(_i64))))
+    return {"arena": counts[1], "form": counts[2], "n_events": counts[3], "allocated": counts[4], "side_eighths": counts[5],
+            "ops": ops[:counts[0], :17]}
 
 
 class Handle:

@@ -185,7 +185,7 @@ struct gpt_handle {
     // per-kernel timing of the last predict (gpt_set_profiling)
     bool profiling = false, pred_mj = false, pred_var = false;
     VarWorkspace vws;              // scratch + cached plan of the variance kernel
-    FitAux fit_aux;                // CU-masked streams + events of the overlapped factor / inverse pipeline
+    FitAux fit_aux;                // CU-masked streams + events of the factor + inverse plan (gpt_fit_plan.h)
     double* lml_partial = nullptr; // partial sums of the LML gradient (grow-only)
     size_t lml_partial_cap = 0;
     unsigned char* cov_buf = nullptr;   // scratch of gpt_predict_cov (grow-only)
@@ -1053,18 +1053,18 @@ int gpt_debug_var_plan(int64_t n_columns, int n_iblocks, int n_tasks, int n_work
     return GPT_OK;
 }
 
-int gpt_debug_fit_plan(int n_padded, int panel, int rec_min, int streams, int64_t* counts, int64_t* ops) {
+int gpt_debug_fit_plan(int n_padded, int form, int panel, int streams, int64_t* counts, int64_t* ops) {
     if (n_padded < 64 || n_padded % 64 != 0 || !counts) return fail(GPT_E_ARG, "gpt_debug_fit_plan: bad argument");
-    const FitPlan pl = fit_plan(n_padded, panel, rec_min, streams);
-    counts[0] = (int64_t)pl.ops.size(); counts[1] = (int64_t)pl.arena; counts[2] = pl.blocked ? 1 : 0; counts[3] = pl.n_events;
-    counts[4] = (int64_t)factor_scratch_doubles_of(n_padded);
+    const FitPlan pl = fit_plan(n_padded, form, panel, streams);
+    counts[0] = (int64_t)pl.ops.size(); counts[1] = (int64_t)pl.arena; counts[2] = pl.form; counts[3] = pl.n_events;
+    counts[4] = (int64_t)factor_scratch_doubles_of(n_padded); counts[5] = pl.side_eighths;
     if (ops)
         for (size_t i = 0; i < pl.ops.size(); ++i) {
             const FitOp& o = pl.ops[i];
-            int64_t* r = ops + 16 * i;
-            r[0] = o.kind; r[1] = o.stream; r[2] = o.off; r[3] = o.n1; r[4] = o.n2; r[5] = o.k0; r[6] = o.kw;
-            r[7] = (int64_t)o.r0; r[8] = (int64_t)o.r0_size; r[9] = (int64_t)o.r1; r[10] = (int64_t)o.r1_size;
-            r[11] = o.wait[0]; r[12] = o.wait[1]; r[13] = o.wait[2]; r[14] = o.record; r[15] = 0;
+            int64_t* r = ops + 18 * i;
+            r[0] = o.kind; r[1] = o.stream; r[2] = o.off; r[3] = o.n1; r[4] = o.n2; r[5] = o.k0; r[6] = o.kw; r[7] = o.row_end; r[8] = o.grp;
+            r[9] = (int64_t)o.r0; r[10] = (int64_t)o.r0_size; r[11] = (int64_t)o.r1; r[12] = (int64_t)o.r1_size;
+            r[13] = o.wait[0]; r[14] = o.wait[1]; r[15] = o.wait[2]; r[16] = o.record; r[17] = 0;
         }
     return GPT_OK;
 }

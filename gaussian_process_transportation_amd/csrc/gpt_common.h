@@ -87,6 +87,7 @@ void launch_dot(hipStream_t s, const double* a, const double* b, int64_t n, doub
 constexpr int FIT_AUX_EVENTS = 256;
 struct FitAux {
     bool tried = false, ok = false;
+    int side_eighths = 0;          // CUs of `side` in eighths of the chip (the split the streams were made for)
     hipStream_t side = nullptr, chain = nullptr;
     hipEvent_t events[FIT_AUX_EVENTS] = {};
 };

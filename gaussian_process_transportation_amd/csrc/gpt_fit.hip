@@ -839,22 +839,8 @@ static void launch_gemm(hipStream_t s, const GemmArgs& g) {
 // the folded block lower triangle).  Everything runs in the caller's stream: running the update beside the next
 // panel's steps was tried twice (a second stream with events; update tiles riding in the step launches) and lost
 // both times — profiles/r01_fit_cholesky_ab.log.
-static int potrf_outer_blocks() {
-    static const int ob = [] {
-        if (const char* e = getenv("GPT_POTRF_OB")) { const int v = atoi(e) / NB; if (v >= 1 && v <= 8) return v; }
-        return 2;
-    }();
-    return ob;
-}
-
-// Blocked Cholesky over the block columns [blk_begin, blk_end) (group-aligned), each group's trailing update over the
-// whole matrix behind it; all launches in `s`.
-static int potrf_group(int NP) {
-    int grp_env = 0;
-    if (const char* e = getenv("GPT_POTRF_GROUP")) { const int v = atoi(e); if (v >= 1 && v <= 8) grp_env = v; }
-    return grp_env ? grp_env : (NP >= 4096 ? 2 : 1);
-}
-
+// (potrf_outer_blocks / potrf_group — panels of OB columns, `grp` panels per trailing update — live in gpt_fit_plan.h: the plan
+// needs them for the split of form 1)
 // Trailing update of the Cholesky: A[row0.., row0..row0+ncols) -= P P^T on the block lower triangle, P = A[row0.., kcol0..kcol0+kw)
 // (rows [row0, row_end): the whole matrix behind row0, or the diagonal block a leaf of the recursive form is confined to)
 static void syrk_update(hipStream_t s, double* K, int NP, int row0, int ncols, int kcol0, int kw, int row_end = -1) {
@@ -959,14 +945,15 @@ void fit_aux_release(FitAux& aux) {
 // round-robin over the XCDs, so both sets span all 8 XCDs (7/8: every XCD keeps 4 CUs for the chain).
 // tools/probes/cumask_probe.hip: a launch chain on one mask and a bulk kernel on the other run side by side without delaying
 // each other, which plain streams do not (a k_potrf_step queues behind a GEMM's grid: 19 -> 68-83 us per step, r04_fit_summary.txt).
-static bool fit_aux_init(FitAux& aux, int n_events) {
-    if (aux.tried) return aux.ok && n_events <= FIT_MAX_EVENTS;
-    aux.tried = true;
+static bool fit_aux_init(FitAux& aux, int n_events, int eighths) {
     if (n_events > FIT_MAX_EVENTS) return false;
+    if (aux.tried && (!aux.ok || aux.side_eighths == eighths)) return aux.ok;
+    if (aux.tried) fit_aux_release(aux);             // a handle that changes size class (or form) gets new streams
+    aux.tried = true;
+    aux.side_eighths = eighths;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, current_device()) != hipSuccess) return false;
     const int ncu = prop.multiProcessorCount;
-    const int eighths = fit_env_int("GPT_FIT_SIDE_EIGHTHS", 7);
     const int n_side = ncu * eighths / 8;
     if (n_side < 16 || ncu - n_side < 8) return false;
     const int words = (ncu + 31) / 32;
@@ -994,14 +981,12 @@ __global__ __launch_bounds__(256) void k_copy2d(const double* __restrict__ src, 
     }
 }
 
-static_assert(FIT_AUX_EVENTS == FIT_MAX_EVENTS, "event pool of a handle = what a plan may ask for");
-// Executes the plan of gpt_fit_plan.h (see there for the algebra, the streams and the events).
+static_assert(NB == FIT_NB && FIT_AUX_EVENTS == FIT_MAX_EVENTS, "event pool of a handle = what a plan may ask for");
+// Executes the plan of gpt_fit_plan.h (see there for the forms, the streams and the events).
 void launch_factor_inverse(hipStream_t s, double* K, double* W, int NP, int* info, double* scratch, FitAux* aux, hipEvent_t ev_factored) {
     FitPlan pl = fit_plan(NP);
-    bool multi = false;
-    for (const FitOp& op : pl.ops) multi = multi || op.stream != FS_MAIN;
-    if (multi && !(aux && fit_aux_init(*aux, pl.n_events))) { pl = fit_plan(NP, -1, -1, 0); multi = false; }     // no masked streams: the serial order
-    const int leaf_grp = pl.blocked ? fit_env_int("GPT_FIT_LEAF_GROUP", 1) : 0;
+    bool multi = pl.multi_stream();
+    if (multi && !(aux && fit_aux_init(*aux, pl.n_events, pl.side_eighths))) { pl = fit_plan(NP, 0); multi = false; }     // no masked streams: one leaf
     for (const FitOp& op : pl.ops) {
         const int off = op.off, b = op.n1, r = op.n2;
         hipStream_t st = !multi ? s : (op.stream == FS_SIDE ? aux->side : (op.stream == FS_CHAIN ? aux->chain : s));
@@ -1009,11 +994,13 @@ void launch_factor_inverse(hipStream_t s, double* K, double* W, int NP, int* inf
             for (int e : op.wait) if (e >= 0) hipStreamWaitEvent(st, aux->events[e], 0);
         double* const Wpp = W + (size_t)off * NP + off;
         switch (op.kind) {
-        case FOP_LEAF_FACTOR:
-            potrf_groups(st, K, W, NP, info, off / NB, (off + b) / NB, (off + b) / NB, leaf_grp);
+        case FOP_POTRF:
+            potrf_groups(st, K, W, NP, info, off / NB, (off + b) / NB, op.row_end / NB, op.grp);
+            break;
+        case FOP_FINISH:
             potrf_finish(st, K, W, NP, off / NB, (off + b) / NB);
             break;
-        case FOP_LEAF_INVERSE:
+        case FOP_TRINV:
             trinv_levels(st, K, W, NP, off, b, scratch + op.r0);
             break;
         case FOP_FACTORED:

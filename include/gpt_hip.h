@@ -212,12 +212,14 @@ int gpt_predict_timings(gpt_handle* h, double* ms_out);
 int gpt_debug_var_plan(int64_t n_columns, int n_iblocks, int n_tasks, int n_workgroups, int order, int64_t* counts,
                        int* item_begin, int* items, int* fin, int* splits);
 
-/* Test hook (host only, no GPU): the plan of the blocked factor + inverse for a padded size (csrc/gpt_fit_plan.h).
- * panel / rec_min / streams < 0: environment or defaults (streams: 1 = main + side + chain, 0 = the serial order).
- * counts[5] = {ops, arena doubles, blocked?, events, doubles the fit workspace allocates (>= arena)}; ops (may be NULL)
- * receives counts[0] rows of 16: kind, stream, off, n1, n2, k0, kw, r0, r0_size, r1, r1_size, wait0, wait1, wait2, record, 0
- * (regions in doubles inside the arena; events by id, -1 = none; FitOpKind and streams in gpt_fit_plan.h). */
-int gpt_debug_fit_plan(int n_padded, int panel, int rec_min, int streams, int64_t* counts, int64_t* ops);
+/* Test hook (host only, no GPU): the plan of the factor + inverse for a padded size (csrc/gpt_fit_plan.h).
+ * form: 0 one leaf, 1 split with the second half's chain beside the first half's inverse, 2 left-looking panels with look-ahead,
+ * < 0: environment / by size; panel (form 2) and streams (1 = CU-masked side and chain streams, 0 = the serial order) < 0:
+ * environment or defaults.  counts[6] = {ops, arena doubles, form, events, doubles the fit workspace allocates (>= arena),
+ * eighths of the CUs given to the side stream}; ops (may be NULL) receives counts[0] rows of 18: kind, stream, off, n1, n2, k0,
+ * kw, row_end, grp, r0, r0_size, r1, r1_size, wait0, wait1, wait2, record, 0 (regions in doubles inside the arena; events by id,
+ * -1 = none; FitOpKind and the streams in gpt_fit_plan.h). */
+int gpt_debug_fit_plan(int n_padded, int form, int panel, int streams, int64_t* counts, int64_t* ops);
 
 #ifdef __cplusplus
 }

@@ -63,17 +63,18 @@ for N, D, O in ((1, 1, 1), (700, 3, 3), (1100, 2, 6), (530, 5, 5), (200, 8, 2), 
         h.fit_timings()
 h.set_dtype(_lib.GPT_F64)
 
-# a size the blocked factor + inverse runs at (csrc/gpt_fit_plan.h): the stand-in replays every scratch region of the plan
-# inside the arena the orchestration allocated — with the plan changing under the handle between two fits
+# a size the multi-stream forms of the factor + inverse run at (csrc/gpt_fit_plan.h): the stand-in replays every scratch region of
+# the plan inside the arena the orchestration allocated — with the plan changing under the handle between two fits
 import os
-for panel in ("512", "2048", None):
-    if panel is None:
-        os.environ.pop("GPT_FIT_PANEL", None)
-    else:
-        os.environ["GPT_FIT_PANEL"] = panel
+for form, panel in (("2", "512"), ("1", None), ("2", "2048"), (None, None)):
+    for k, v in (("GPT_FIT_FORM", form), ("GPT_FIT_PANEL", panel)):
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
     Xb = rng.uniform(0, 1, (4200, 3))
     h.fit(Xb, rng.standard_normal((4200, 2)), np.full(3, 0.3), 1.0, 1e-2, 1e-10)
-    assert _lib.debug_fit_plan(4608)["blocked"]
+    assert _lib.debug_fit_plan(4608)["form"] == int(form or 1)
 h2 = _lib.Handle(0)
 h2.factor_copy_from(h)                      # one-process replica (gpt_factor_copy)
 assert h2.info() == h.info() and h2.model_info() == h.model_info()

@@ -1520,11 +1520,13 @@ def test_devices_argument_shards_rows_over_the_handles_of_one_process():
 
 
 @pytest.mark.parametrize("N", [4200, 5300])
-def test_blocked_factor_and_inverse_across_panel_widths(N, monkeypatch):
-    """The blocked form of the factor + inverse (csrc/gpt_fit_plan.h: left-looking panels, look-ahead updates and the inverse on
-    a side stream, leaves on a chain stream) — L against LAPACK, W L = I, alpha, the pivot of a matrix that stops being positive
-    definite in the LAST panel, for three panel widths (the plan — and the scratch arena it needs — changes under ONE handle
-    between fits), with the three streams and in the serial order, and the one-leaf form (GPT_FIT_BLOCKED=0) beside them."""
+def test_factor_and_inverse_forms_against_lapack(N, monkeypatch):
+    """Every form of the factor + inverse plan (csrc/gpt_fit_plan.h) on ONE handle, the plan — and the scratch arena it needs —
+    changing between fits: the shipped split form (second half's launch chain beside the first half's inverse on CU-masked
+    streams), the same with a group width that moves the split OFF the half (GPT_POTRF_GROUP=4: N = 5300 -> h = 2560, r = 3072,
+    the shape that wrote past a half-sized scratch region in round 3 — VERDICT r3 item 3), the one-leaf form, and the opt-in
+    left-looking form for three panel widths, with streams and in the serial order.  L against LAPACK, W L = I, alpha; the pivot
+    of a matrix that stops being positive definite late in the second half."""
     import scipy.linalg
     from gaussian_process_transportation_amd import _lib
     from oracle import gp_oracle as orc
@@ -1537,28 +1539,33 @@ def test_blocked_factor_and_inverse_across_panel_widths(N, monkeypatch):
     aref = scipy.linalg.cho_solve((Lref, True), Y)
     NP = (N + 511) // 512 * 512
     h = _lib.Handle(0)
-    Ls = []
-    for panel, overlap, blocked in (("512", "1", "1"), ("2048", "0", "1"), ("1024", "1", "1"), ("1024", "1", "0")):
-        monkeypatch.setenv("GPT_FIT_PANEL", panel)
-        monkeypatch.setenv("GPT_FIT_OVERLAP", overlap)
-        monkeypatch.setenv("GPT_FIT_BLOCKED", blocked)
-        assert _lib.debug_fit_plan(NP)["blocked"] == (blocked == "1")
-        h.fit(X, Y, ls, c, noise, jit)
-        L, alpha = h.export()
-        assert_parity(L, Lref, 1e-11, f"L_ (panel {panel}, streams {overlap}, blocked {blocked})")
-        assert_parity(alpha, aref, 1e-7, f"alpha_ (panel {panel})")
-        W = h.export_inverse_factor()
-        assert np.abs(W @ Lref - np.eye(N)).max() < 1e-9
-        Ls.append(L)
-        h.fit(X, Y, ls, c, noise, jit)                       # streams and events are reused by the next fit
-        assert np.array_equal(h.export()[0], L)
     Sigma = 1e-3 * np.eye(N)
     Sigma[N - 300, N - 300] = -2.0
-    for blocked in ("1", "0"):
-        monkeypatch.setenv("GPT_FIT_BLOCKED", blocked)
+    #        form  panel   overlap  potrf group
+    cases = [("1", None, "1", None), ("1", None, "1", "4"), ("0", None, "1", None), ("2", "512", "1", None), ("2", "2048", "0", None),
+             ("2", "1024", "1", None), (None, None, "1", None)]
+    for form, panel, overlap, group in cases:
+        for k, v in (("GPT_FIT_FORM", form), ("GPT_FIT_PANEL", panel), ("GPT_FIT_OVERLAP", overlap), ("GPT_POTRF_GROUP", group)):
+            if v is None:
+                monkeypatch.delenv(k, raising=False)
+            else:
+                monkeypatch.setenv(k, v)
+        pl = _lib.debug_fit_plan(NP)
+        assert pl["form"] == int(form or 1)
+        if group == "4" and N == 5300:
+            assert [int(o[2]) for o in pl["ops"] if _lib.FIT_OP_KINDS[int(o[0])] == "T"] == [2560]      # the split is off the half
+        what = f"form {form}, panel {panel}, streams {overlap}, group {group}"
+        h.fit(X, Y, ls, c, noise, jit)
+        L, alpha = h.export()
+        assert_parity(L, Lref, 1e-11, f"L_ ({what})")
+        assert_parity(alpha, aref, 1e-7, f"alpha_ ({what})")
+        W = h.export_inverse_factor()
+        assert np.abs(W @ Lref - np.eye(N)).max() < 1e-9, what
+        h.fit(X, Y, ls, c, noise, jit)                       # streams and events are reused by the next fit
+        assert np.array_equal(h.export()[0], L), what
         with pytest.raises(np.linalg.LinAlgError) as ei:
             h.fit_noise_matrix(X, Y, ls, c, Sigma)
-        assert int(str(ei.value).split("pivot")[1].split()[0]) == N - 300 + 1
+        assert int(str(ei.value).split("pivot")[1].split()[0]) == N - 300 + 1, what
     h.close()
 
 

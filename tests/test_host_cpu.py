@@ -472,18 +472,19 @@ def test_hyperparameter_search_driver_sequential_and_concurrent(monkeypatch):
 
 
 # ---------------------------------------------------------------------------------------------------------------
-# Plan of the blocked factor + inverse (csrc/gpt_fit_plan.h): host code, replayed here for every padded size
-def _fit_op_accesses(o, NP):
+# Plan of the factor + inverse (csrc/gpt_fit_plan.h): host code, replayed here for every padded size and form
+def _fit_op_accesses(f, NP):
     """(reads, writes) of one plan op as rectangles (matrix, row0, row1, col0, col1); scratch regions as ('S', a, b, 0, 1)."""
-    from gaussian_process_transportation_amd import _lib
-    f = dict(zip(_lib.FIT_OP_FIELDS, (int(v) for v in o)))
-    kind = _lib.FIT_OP_KINDS[f["kind"]]
+    kind = f["kind_name"]
     off, b, r = f["off"], f["n1"], f["n2"]
     diagK, diagW = ("K", off, off + b, off, off + b), ("W", off, off + b, off, off + b)
     S0, S1 = ("S", f["r0"], f["r0"] + f["r0_size"], 0, 1), ("S", f["r1"], f["r1"] + f["r1_size"], 0, 1)
-    if kind == "LEAF_FACTOR":
+    if kind == "POTRF":                  # right-looking: the columns and everything their trailing updates reach; L_kk parked in W
+        tr = ("K", off, f["row_end"], off, f["row_end"])
+        return [tr, diagW], [tr, diagW]
+    if kind == "FINISH":
         return [diagK, diagW], [diagK, diagW]
-    if kind == "LEAF_INVERSE":
+    if kind == "TRINV":
         return [diagK, diagW, S0], [diagW, S0]
     if kind == "UPDATE":
         C = ("K", off, NP, off, off + b)
@@ -503,73 +504,86 @@ def _overlap(a, b):
     return a[0] == b[0] and a[1] < b[2] and b[1] < a[2] and a[3] < b[4] and b[3] < a[4]
 
 
-def _check_fit_plan(NP, panel, rec_min, streams):
+def _trinv_extent(n):
+    ext, sz = 0, 64                      # what trinv_levels really touches
+    while sz < n:
+        npairs = (n + 2 * sz - 1) // (2 * sz)
+        m_last = n - (npairs - 1) * 2 * sz - sz
+        nbp = npairs
+        if m_last <= 0:
+            nbp, m_last = npairs - 1, sz
+        if nbp > 0:
+            ext = max(ext, (nbp - 1) * sz * sz + min(m_last, sz) * sz)
+        sz *= 2
+    return ext
+
+
+def _check_fit_plan(NP, form, panel, streams):
     from gaussian_process_transportation_amd import _lib
-    K = {k: i for i, k in enumerate(_lib.FIT_OP_KINDS)}
-    F = {k: i for i, k in enumerate(_lib.FIT_OP_FIELDS)}
-    pl = _lib.debug_fit_plan(NP, panel, rec_min, streams)
-    ops, arena = pl["ops"], pl["arena"]
+    pl = _lib.debug_fit_plan(NP, form, panel, streams)
+    arena = pl["arena"]
+    ops = []
+    for row in pl["ops"]:
+        f = dict(zip(_lib.FIT_OP_FIELDS, (int(v) for v in row)))
+        f["kind_name"] = _lib.FIT_OP_KINDS[f["kind"]]
+        ops.append(f)
     n = len(ops)
-    if panel < 0 and rec_min < 0 and streams < 0:
+    if form < 0 and panel < 0 and streams < 0:
         assert pl["allocated"] >= arena          # what the fit workspace allocates for the plan the environment selects
-    # ---- regions inside the arena, panels tile the diagonal, updates cover exactly the columns in front of their panel
-    leaves, upd = [], {}
-    for o in ops:
+    assert pl["allocated"] >= _lib.debug_fit_plan(NP, 0)["arena"]       # ... and for the one-leaf form it may fall back to
+    # ---- regions inside the arena; what is factored, finished and inverted tiles the diagonal exactly
+    cover = {"POTRF": [], "FINISH": [], "TRINV": []}
+    upd = {}
+    for f in ops:
         for reg in ("r0", "r1"):
-            a, sz = int(o[F[reg]]), int(o[F[reg + "_size"]])
-            assert 0 <= a and a + sz <= arena, (NP, panel, reg)
-        off, b, r = int(o[F["off"]]), int(o[F["n1"]]), int(o[F["n2"]])
+            assert 0 <= f[reg] and f[reg] + f[reg + "_size"] <= arena, (NP, form, panel, f)
+        off, b, r = f["off"], f["n1"], f["n2"]
         assert 0 <= off and off + b + r <= NP and b % 64 == 0
-        if int(o[0]) == K["LEAF_FACTOR"]:
-            leaves.append((off, off + b))
-        if int(o[0]) == K["LEAF_INVERSE"]:
-            ext, sz = 0, 64                      # what trinv_levels really touches
-            while sz < b:
-                npairs = (b + 2 * sz - 1) // (2 * sz)
-                m_last = b - (npairs - 1) * 2 * sz - sz
-                nbp = npairs
-                if m_last <= 0:
-                    nbp, m_last = npairs - 1, sz
-                if nbp > 0:
-                    ext = max(ext, (nbp - 1) * sz * sz + min(m_last, sz) * sz)
-                sz *= 2
-            assert int(o[F["r0_size"]]) >= ext
-        if int(o[0]) == K["UPDATE"]:
+        if f["kind_name"] in cover:
+            cover[f["kind_name"]].append((off, off + b))
+        if f["kind_name"] == "POTRF":
+            assert off + b <= f["row_end"] <= NP and f["row_end"] % 64 == 0
+        if f["kind_name"] == "TRINV":
+            assert f["r0_size"] >= _trinv_extent(b)
+        if f["kind_name"] == "UPDATE":
             assert off + b + r == NP
-            upd.setdefault(off, []).append((int(o[F["k0"]]), int(o[F["k0"]]) + int(o[F["kw"]])))
-        if int(o[0]) == K["TRSM"]:
-            assert int(o[F["r0_size"]]) == b * r and off + b + r == NP
-        if int(o[0]) == K["T"]:
-            assert int(o[F["r1_size"]]) == b * off
-    assert leaves[0][0] == 0 and leaves[-1][1] == NP and all(leaves[i][1] == leaves[i + 1][0] for i in range(len(leaves) - 1))
-    for off, _ in leaves[1:]:
-        ks = sorted(upd[off])
-        assert ks[0][0] == 0 and ks[-1][1] == off and all(ks[i][1] == ks[i + 1][0] for i in range(len(ks) - 1)), "updates must cover [0, off) once"
-    assert sum(1 for o in ops if int(o[0]) == K["FACTORED"]) == 1
-    if not pl["blocked"]:
-        assert len(leaves) == 1
-        return pl
-    assert sum(1 for o in ops if int(o[0]) == K["WFIN"]) == len(leaves) - 1 == sum(1 for o in ops if int(o[0]) == K["T"])
+            upd.setdefault(off, []).append((f["k0"], f["k0"] + f["kw"]))
+        if f["kind_name"] == "TRSM":
+            assert f["r0_size"] == b * r and off + b + r == NP
+        if f["kind_name"] in ("T", "WFIN"):
+            assert f["r1_size"] == b * off
+    for k, cov in cover.items():
+        cov.sort()
+        if k == "TRINV" and pl["form"] == 1:
+            continue                             # (the two halves; their off-diagonal block comes from T / WFIN)
+        assert cov[0][0] == 0 and cov[-1][1] == NP and all(cov[i][1] == cov[i + 1][0] for i in range(len(cov) - 1)), (k, cov)
+    if pl["form"] == 2:
+        for off, _ in cover["POTRF"][1:]:
+            ks = sorted(upd[off])
+            assert ks[0][0] == 0 and ks[-1][1] == off and all(ks[i][1] == ks[i + 1][0] for i in range(len(ks) - 1)), "updates must cover [0, off) once"
+        assert sum(f["kind_name"] == "WFIN" for f in ops) == len(cover["POTRF"]) - 1 == sum(f["kind_name"] == "T" for f in ops)
+    if pl["form"] == 1:
+        (h0, h1), (r0, r1) = cover["TRINV"]
+        assert h0 == 0 and h1 == r0 and r1 == NP
+        assert [(f["off"], f["n1"]) for f in ops if f["kind_name"] in ("T", "WFIN")] == [(h1, NP - h1)] * 2
+    assert sum(f["kind_name"] == "FACTORED" for f in ops) == 1
     # ---- happens-before from (stream order + events) must order every pair of ops that touch overlapping memory
     hb = np.zeros((n, n), dtype=bool)
     last_on, recorded = {}, {}
-    for i, o in enumerate(ops):
-        st = int(o[F["stream"]])
-        if st in last_on:
-            hb[last_on[st], i] = True
-        last_on[st] = i
+    for i, f in enumerate(ops):
+        if f["stream"] in last_on:
+            hb[last_on[f["stream"]], i] = True
+        last_on[f["stream"]] = i
         for w in ("wait0", "wait1", "wait2"):
-            e = int(o[F[w]])
-            if e >= 0:
-                assert e in recorded, "wait for an event nobody has recorded yet"
-                hb[recorded[e], i] = True
-        e = int(o[F["record"]])
-        if e >= 0:
-            assert e not in recorded and e < pl["n_events"]
-            recorded[e] = i
+            if f[w] >= 0:
+                assert f[w] in recorded, "wait for an event nobody has recorded yet"
+                hb[recorded[f[w]], i] = True
+        if f["record"] >= 0:
+            assert f["record"] not in recorded and f["record"] < pl["n_events"] <= 256
+            recorded[f["record"]] = i
     for k in range(n):                           # transitive closure (ops are in issue order: edges go forward)
         hb[:, :] |= np.outer(hb[:, k], hb[k, :])
-    acc = [_fit_op_accesses(o, NP) for o in ops]
+    acc = [_fit_op_accesses(f, NP) for f in ops]
     for i in range(n):
         for j in range(i + 1, n):
             if hb[i, j]:
@@ -577,36 +591,57 @@ def _check_fit_plan(NP, panel, rec_min, streams):
             ri, wi = acc[i]
             rj, wj = acc[j]
             clash = any(_overlap(a, b) for a in wi for b in rj + wj) or any(_overlap(a, b) for a in ri for b in wj)
-            assert not clash, (NP, panel, "unordered ops touch the same memory", _lib.FIT_OP_KINDS[int(ops[i][0])], ops[i].tolist(),
-                               _lib.FIT_OP_KINDS[int(ops[j][0])], ops[j].tolist())
+            assert not clash, (NP, form, panel, "unordered ops touch the same memory", ops[i], ops[j])
     # the caller continues in the main stream: its last op must come after everything
-    main = [i for i, o in enumerate(ops) if int(o[F["stream"]]) == 0]
+    main = [i for i, f in enumerate(ops) if f["stream"] == 0]
     assert all(i == main[-1] or hb[i, main[-1]] for i in range(n)), "work left unjoined when launch_factor_inverse returns"
-    return pl
+    return pl, ops
 
 
-def test_fit_plan_regions_and_ordering_for_every_size():
-    """Round 3 ended with a GPU memory fault from a scratch layout that assumed a half split; that code is
-    gone.  The blocked form's layout is produced by the walk that sizes the arena, and its cross-stream order by explicit
-    events: this replays both for every padded size up to 16384 and four panel widths — every region inside the arena, the
-    panels tiling the diagonal, the updates covering the columns in front of each panel exactly once, and the happens-before
-    relation of (stream order + events) ordering EVERY pair of operations that touch overlapping memory (K, W or scratch), in the
-    three-stream form and in the serial one; nothing left unjoined at the end."""
-    n_blocked = 0
+def test_fit_plan_regions_and_ordering_for_every_size_and_form(monkeypatch):
+    """Round 3 ended with a GPU memory fault from a scratch layout that assumed a half split.  Layout and
+    cross-stream order of the factor + inverse are now DATA (csrc/gpt_fit_plan.h), and this replays them for every padded size up
+    to 16384, the three forms, four panel widths and the group widths that move form 1's split off the half — every region
+    inside the arena (and inside what the workspace allocates), the factored / finished / inverted blocks tiling the diagonal,
+    form 2's updates covering the columns in front of each panel exactly once, and the happens-before relation of (stream order
+    + events) ordering EVERY pair of operations that touch overlapping memory (K, W or scratch), with the CU-masked streams and
+    in the serial order; nothing left unjoined at the end."""
+    seen = {0: 0, 1: 0, 2: 0}
     for NP in range(512, 16384 + 1, 512):
-        for panel in (512, 1024, 1536, 2048):
-            for rec_min, streams in ((4096, 1), (0, 1), (0, 0)):
-                if NP > 8192 and (panel == 512 or rec_min == 0):
-                    continue                     # (keeps the closure small; the large sizes run with the shipped thresholds)
-                n_blocked += _check_fit_plan(NP, panel, rec_min, streams)["blocked"]
-    assert n_blocked > 100
-    for NP in (512, 4096, 4608, 8192, 12288):
-        _check_fit_plan(NP, -1, -1, -1)
-    pl = _check_fit_plan(8192, 1024, 4096, 1)
-    kinds = [int(o[0]) for o in pl["ops"]]
-    assert kinds.count(0) == 8 and kinds.count(2) == 7 + 6 and kinds.count(3) == 7        # 8 leaves; 7 last + 6 look-ahead updates; 7 TRSMs
-    streams = {int(o[1]) for o in pl["ops"]}
-    assert streams == {0, 1, 2} and {int(o[1]) for o in _check_fit_plan(8192, 1024, 4096, 0)["ops"]} == {0}
+        for form in (-1, 0, 1, 2):
+            for panel in ((512, 1024, 1536, 2048) if form == 2 else (-1,)):
+                for streams in (1, 0):
+                    if form == 2 and NP > 8192 and panel == 512:
+                        continue                 # (keeps the closure small)
+                    pl, _ = _check_fit_plan(NP, form, panel, streams)
+                    seen[pl["form"]] += 1
+    assert min(seen.values()) > 40
+    # the shipped choice: split where the second half is chain-bound, one leaf elsewhere
+    assert [_lib_form(NP) for NP in (512, 4096, 4608, 8192, 12288, 12800, 16384)] == [0, 0, 1, 1, 1, 0, 0]
+    pl, ops = _check_fit_plan(8192, -1, -1, -1)
+    assert pl["form"] == 1 and pl["side_eighths"] == 5 and {f["stream"] for f in ops} == {0, 1, 2}
+    assert [f["off"] for f in ops if f["kind_name"] == "T"] == [4096]
+    assert _check_fit_plan(5632, -1, -1, -1)[0]["side_eighths"] == 4
+    # group widths that move the split off the half (GPT_POTRF_GROUP = 4: NP = 5632 -> h = 2560, r = 3072 — the shape of round 3's
+    # fault): the arena follows the split
+    monkeypatch.setenv("GPT_POTRF_GROUP", "4")
+    for NP in range(4608, 12288 + 1, 512):
+        pl, ops = _check_fit_plan(NP, -1, -1, -1)
+        if pl["form"] == 1:
+            h = [f["off"] for f in ops if f["kind_name"] == "T"][0]
+            assert h % (4 * 128) == 0 and pl["arena"] >= (NP - h) * h + _trinv_extent(max(h, NP - h))
+    pl, ops = _check_fit_plan(5632, -1, -1, -1)
+    assert [f["off"] for f in ops if f["kind_name"] == "T"] == [2560]
+    monkeypatch.delenv("GPT_POTRF_GROUP")
+    pl, ops = _check_fit_plan(8192, 2, 1024, 1)
+    kinds = [f["kind_name"] for f in ops]
+    assert kinds.count("POTRF") == 8 and kinds.count("UPDATE") == 7 + 6 and kinds.count("TRSM") == 7      # 8 panels; 7 last + 6 look-ahead updates
+    assert {f["stream"] for f in ops} == {0, 1, 2} and {f["stream"] for f in _check_fit_plan(8192, 2, 1024, 0)[1]} == {0}
+
+
+def _lib_form(NP):
+    from gaussian_process_transportation_amd import _lib
+    return _lib.debug_fit_plan(NP)["form"]
 
 
 class _FakeHandle:
