@@ -156,7 +156,7 @@ def vptr(a):
 def debug_var_plan(n_columns, n_iblocks, n_tasks, n_workgroups, order=-1):
     """The work decomposition of the variance kernel (csrc/gpt_plan.h) as numpy arrays; host code, no GPU."""
     lib = load()
-    counts = (_i64 * 8)()
+    counts = (_i64 * 12)()
     ip = C.POINTER(C.c_int)
     check(lib.gpt_debug_var_plan(n_columns, n_iblocks, n_tasks, n_workgroups, order, counts, None, None, None, None))
     item_begin = np.zeros(n_workgroups + 1, dtype=np.int32)
@@ -166,7 +166,8 @@ def debug_var_plan(n_columns, n_iblocks, n_tasks, n_workgroups, order=-1):
     check(lib.gpt_debug_var_plan(n_columns, n_iblocks, n_tasks, n_workgroups, order, counts, item_begin.ctypes.data_as(ip),
                                  items.ctypes.data_as(ip), fin.ctypes.data_as(ip), splits.ctypes.data_as(ip)))
     return {"n_items": counts[0], "n_splits": counts[1], "n_slots": counts[2], "n_vslots": counts[3], "ncb": counts[4],
-            "nfull": counts[5], "order": counts[7], "item_begin": item_begin, "items": items[:counts[0]],
+            "nfull": counts[5], "order": counts[7], "cohorts": bool(counts[8]), "cohort_s": counts[9], "cohort_f": counts[10],
+            "item_begin": item_begin, "items": items[:counts[0]],
             "fin": fin[:counts[6]], "splits": splits[:counts[1]]}
 
 

@@ -817,15 +817,12 @@ static int gemm_tile32_threshold() {
 template <bool BT, bool AT = false>
 static void launch_gemm(hipStream_t s, const GemmArgs& g) {
     const int Mmax = g.nbatch == 1 ? g.M_last : (g.M > g.M_last ? g.M : g.M_last);
-    const int tm = (Mmax + 127) / 128, tn = (g.N + 127) / 128;
-    double tiles = (double)g.nbatch * tm * tn;
-    if (g.lower_only) tiles -= 0.5 * (tn < tm ? tn : tm) * ((tn < tm ? tn : tm) - 1);     // the tiles above the diagonal of the leading square
-    // 32-tiles pay four times the operand traffic per flop of a 64-tile: they are for products whose tiles are SHORT chains (rank
-    // 128/256 updates, the small levels of a leaf's inverse).  With K >= 1024 a 64-tile is 25 us of work and a few hundred of
-    // them fill the chip (the 2048^2 x 2048 products of the blocked form: 238 us on 32-tiles, 36 TFLOP/s, against 163-182 us on
-    // 64-tiles for the same flops: profiles/r04_fit_summary.txt)
-    const int Kmax = g.K > g.K_last ? g.K : g.K_last;
-    const double thr32 = Kmax >= 1024 ? 256.0 : (double)gemm_tile32_threshold();
+    double tiles = (double)g.nbatch * ((Mmax + 127) / 128) * ((g.N + 127) / 128);
+    if (g.lower_only) tiles *= 0.5;
+    // (round 4 tried 64-tiles for every product with K >= 1024 — on the theory that a deep 64-tile is 25 us of work and a few hundred
+    // fill the chip: the N = 2500 inverse went 0.23 -> 0.32 ms and its K^-1 = W^T W 149 -> 209 us.  Few tiles, whatever their depth,
+    // want the small tile: profiles/r04_fit_summary.txt)
+    const double thr32 = (double)gemm_tile32_threshold();
     if (4.0 * tiles < thr32 && gemm_body() == 0) launch_gemm_ts<BT, AT, 32>(s, g);
     else if (tiles < gemm_tile_threshold()) launch_gemm_ts<BT, AT, 64>(s, g);
     else launch_gemm_ts<BT, AT, 128>(s, g);

