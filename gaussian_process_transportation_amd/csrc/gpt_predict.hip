@@ -324,7 +324,7 @@ template <typename T> constexpr size_t var_lds_bytes() {
     return (El<T>::DIAG_LDS && image > chunks) ? image : chunks;
 }
 
-template <typename T, int NCOMP, bool CROSS, int KT, int DW = 3, bool KSTAR = true>
+template <typename T, int NCOMP, bool CROSS, int KT, int DW = 3, bool KSTAR = true, bool HALF = false>
 __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, const T* __restrict__ Xs,
                                                 const T* __restrict__ Wf, const T* __restrict__ Xq,
                                                 int64_t M, T* __restrict__ slab, T* __restrict__ vslab, T* __restrict__ bscratch) {
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
             // staged: the four exps of a lane stage by stage (gpt_exp.h kernel_tab4: their latencies overlap — the openings of a
             // sweep, where no MFMA hides them); not staged: one after the other, as few live registers as possible (inside the
             // MFMA loop, where the staged form spills)
-            auto produce_to = [&](auto lds_tag, auto staged_tag, const int buf, const int k4) {
+            auto produce_to = [&](auto lds_tag, auto staged_tag, const int buf, const int k4, const bool to_scr = true) {
                 constexpr bool to_lds = decltype(lds_tag)::value;
                 constexpr bool staged = decltype(staged_tag)::value;
                 T* dstl = Bs(buf, k4 % VAR_CH);
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
                         b[t] = (NCOMP == 1) ? kv[t] : kv[t] * (cbv + sc_own * (xo - qs[own_d][qi]));
                     }
                     if (to_lds) *reinterpret_cast<v4*>(dstl) = b;
-                    (buni + (size_t)k4 * 64)[lane] = b;
+                    if (to_scr) (buni + (size_t)k4 * 64)[lane] = b;
                 } else if (GEN) {
                     const T x0 = gx[0] * RS2, x1 = gx[1] * RS2, x2 = gx[2] * RS2;
                     v4 b;
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
                         }
                     }
                     if (to_lds) *reinterpret_cast<v4*>(dstl) = b;
-                    if (GPT_ABL != 8) (buni + (size_t)k4 * 64)[lane] = b;
+                    if (GPT_ABL != 8 && to_scr) (buni + (size_t)k4 * 64)[lane] = b;
                 } else {
                     *reinterpret_cast<v4*>(dstl) = bl;
                 }
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
             auto produce = [&](const int buf, const int k4) { produce_to(std::true_type{}, std::false_type{}, buf, k4); };
             // GEN: `cnt` k-steps k4_0 + j * stride generated with their source loads in flight together (load -> wait -> exp ->
             // store one at a time cost 9.5 k cycles per k-step at the opening of a sweep: profiles/r04_small_n.txt)
-            auto generate_batch = [&](auto lds_tag, auto cnt_tag, const int buf, const int k4_0, const int stride) {
+            auto generate_batch = [&](auto lds_tag, auto cnt_tag, const int buf, const int k4_0, const int stride, const bool to_scr = true) {
                 constexpr int cnt = decltype(cnt_tag)::value;
                 T bx[cnt][DW], bo[cnt];
 #pragma unroll
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
 #pragma unroll
                     for (int d = 0; d < DW; ++d) gx[d] = bx[j][d];
                     gx_own = bo[j];
-                    produce_to(lds_tag, std::integral_constant<bool, GPT_GEN_STAGED_EXP != 0>{}, buf, k4_0 + j * stride);
+                    produce_to(lds_tag, std::integral_constant<bool, GPT_GEN_STAGED_EXP != 0>{}, buf, k4_0 + j * stride, to_scr);
                 }
             };
 
@@ -586,7 +586,10 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
             constexpr bool DIAG_FREE = !GEN || GPT_GEN_DIAG_FREE != 0;
             const int lock_end = ((!DIAG_FREE || !has_diag) ? k_hi : VAR_KQ * ib) * VAR_CH;
             const int ch0 = K0 / VAR_CH, ch1 = lock_end / VAR_CH;              // lock-step chunks [ch0, ch1)
-            if (GEN && DIAG_FREE && has_diag && GPT_ABL != 3) {
+            // fp64, small models (HALF: its own instantiation of the kernel, so that the N = 8192 kernel keeps its code and registers):
+            // the first 64 k-steps of a diagonal tile's B image go through LDS — see the tile below
+            constexpr bool half = HALF && !El<T>::DIAG_LDS;
+            if (GEN && DIAG_FREE && has_diag && GPT_ABL != 3 && !half) {
                 // 128 k-steps, 16 per wave (w, w + 8, ...), VALU only; complete and visible before the barrier below
                 const int kd0 = ib * WT_K4;
 #pragma unroll 1
@@ -739,7 +742,73 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
                         b = (bp + (size_t)kk * 64)[lane];
                     };
                     constexpr int R = GPT_DIAG_RING;                     // 2: the round-1 .. 3 loop, kept for A/B
-                    if constexpr (R == 2) {
+                    if constexpr (half) {
+                        // Small models (N <= 2560): the B images of an XCD's 32 workgroups (0.5 MB each at N = 1024) do not stay in its
+                        // 4 MB of L2, a diagonal tile read straight from the scratch image is 576 wave-steps x 2 KiB from beyond L2, the
+                        // wave that is alone on its SIMD runs at the latency of those reads, and the 256 KB a generating sweep writes
+                        // for its own diagonal tile leave 256 workgroups at the same moment (60 000 clocks per opening:
+                        // profiles/r04_small_n.txt).  Here the first 64 k-steps of the tile's image — all that waves 0..3 need, half of
+                        // what waves 4..7 need — sit in LDS (the chunk buffers are free: the last lock-step barrier has passed): a
+                        // generating sweep produces them there (and in the scratch image only when a later sweep will reload them), a
+                        // reload sweep copies them from the scratch image ONCE, 8 k-steps per wave; steps 64.. still come from the
+                        // scratch image, R blocks ahead.  Two barriers per tile (at N = 8192, where the image is L2-resident, that was
+                        // a loss of 1.1 %: r02_kvar_diag_image_fp64.txt — hence by size).
+                        v4* const img = reinterpret_cast<v4*>(Bs_dyn);    // [k-step 0..64)[lane] = Bs(buf = k / 32, k % 32)
+                        if constexpr (GEN) {
+                            const bool priv = it < n_implicit && pl.ntask == 1;      // the top sweep's own tile: nobody reloads these k-steps
+#pragma unroll 1
+                            for (int j0 = 0; j0 < 8; j0 += 4) {          // k-steps kd0 + w + 8 j, j < 8: below 64 -> LDS
+                                const int k = kd0 + w + VAR_SUB * j0;
+                                generate_batch(std::true_type{}, std::integral_constant<int, 4>{}, (k - kd0) / VAR_CH, k, VAR_SUB, !priv);
+                            }
+#pragma unroll 1
+                            for (int j0 = 8; j0 < 16; j0 += 4)           // 64 .. 127 -> scratch image
+                                generate_batch(std::false_type{}, std::integral_constant<int, 4>{}, 0, kd0 + w + VAR_SUB * j0, VAR_SUB);
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        } else {
+#pragma unroll
+                            for (int hh = 0; hh < 2; ++hh) {
+                                v4 r[4];
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) r[j] = (bp + (size_t)(w + 8 * (4 * hh + j)) * 64)[lane];
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) img[(w + 8 * (4 * hh + j)) * 64 + lane] = r[j];
+                            }
+                        }
+                        __syncthreads();
+                        AF a[R];
+                        v4 b[R];
+#pragma unroll
+                        for (int i = 0; i < R; ++i) ldA(a[i], i);
+                        const int l1 = limit < 64 ? limit : 64;
+                        v4 b_nxt = img[lane];
+                        for (int k4 = 0; k4 < l1; k4 += R) {
+#pragma unroll
+                            for (int i = 0; i < R; ++i) {
+                                const v4 bb = b_nxt;
+                                const int kn = (k4 + i + 1 < l1) ? (k4 + i + 1) : (l1 - 1);
+                                b_nxt = img[kn * 64 + lane];
+                                __builtin_amdgcn_sched_barrier(0);
+                                El<T>::mfma16(acc, a[i], bb);
+                                __builtin_amdgcn_sched_barrier(0);
+                                ldA(a[i], k4 + i + R);
+                            }
+                        }
+                        if (limit > 64) {
+#pragma unroll
+                            for (int i = 0; i < R; ++i) ldB(b[i], 64 + i);
+                        }
+                        for (int k4 = 64; k4 < limit; k4 += R) {
+#pragma unroll
+                            for (int i = 0; i < R; ++i) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                El<T>::mfma16(acc, a[i], b[i]);
+                                __builtin_amdgcn_sched_barrier(0);
+                                ldA(a[i], k4 + i + R); ldB(b[i], k4 + i + R);
+                            }
+                        }
+                        __syncthreads();                                  // the image is free again (next sweep's first fill)
+                    } else if constexpr (R == 2) {
                         AF a0, a1;
                         v4 b0, b1;
                         ldA(a0, 0); ldA(a1, 1); ldB(b0, 0);
@@ -950,6 +1019,17 @@ static void var_kernel_setup() {
                          reinterpret_cast<const void*>(k_var<T, 16, true, KT_RBF, MAX_D>), reinterpret_cast<const void*>(k_var<T, 16, false, KT_RBF, MAX_D>),
                          reinterpret_cast<const void*>(k_var<T, 4, false, KT_RBF, MAX_D, false>), reinterpret_cast<const void*>(k_var<T, 8, false, KT_RBF, MAX_D, false>)};
     for (const void* f : fns) hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)var_lds_bytes<T>());
+    if constexpr (std::is_same<T, double>::value) {       // the small-model instantiations (HALF): launch_var_t
+        const void* hf[] = {reinterpret_cast<const void*>(k_var<T, 1, false, KT_RBF, 3, true, true>), reinterpret_cast<const void*>(k_var<T, 4, true, KT_RBF, 3, true, true>),
+                            reinterpret_cast<const void*>(k_var<T, 4, false, KT_RBF, 3, true, true>), reinterpret_cast<const void*>(k_var<T, 3, false, KT_RBF, 3, true, true>),
+                            reinterpret_cast<const void*>(k_var<T, 1, false, KT_MATERN12, 3, true, true>), reinterpret_cast<const void*>(k_var<T, 1, false, KT_MATERN32, 3, true, true>),
+                            reinterpret_cast<const void*>(k_var<T, 1, false, KT_MATERN52, 3, true, true>),
+                            reinterpret_cast<const void*>(k_var<T, 1, false, KT_RBF, MAX_D, true, true>), reinterpret_cast<const void*>(k_var<T, 1, false, KT_MATERN12, MAX_D, true, true>),
+                            reinterpret_cast<const void*>(k_var<T, 1, false, KT_MATERN32, MAX_D, true, true>), reinterpret_cast<const void*>(k_var<T, 1, false, KT_MATERN52, MAX_D, true, true>),
+                            reinterpret_cast<const void*>(k_var<T, 8, true, KT_RBF, MAX_D, true, true>), reinterpret_cast<const void*>(k_var<T, 8, false, KT_RBF, MAX_D, true, true>),
+                            reinterpret_cast<const void*>(k_var<T, 16, true, KT_RBF, MAX_D, true, true>), reinterpret_cast<const void*>(k_var<T, 16, false, KT_RBF, MAX_D, true, true>)};
+        for (const void* f : hf) hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)var_lds_bytes<T>());
+    }
     });
 }
 
@@ -986,18 +1066,27 @@ static void launch_var_t(hipStream_t s, const KernelParams& p, const VarWorkspac
     const int64_t rpl_scaled = tiles_per_round > 0 ? ((int64_t)rpl_set * 136 + tiles_per_round - 1) / tiles_per_round : rpl_set;
     int64_t rpl = rpl_set > 0 ? (rpl_scaled > rpl_set ? rpl_scaled : rpl_set) : (rounds > 0 ? rounds : 1);
     if (const char* e = getenv("GPT_VAR_ROUNDS_EXACT")) { if (atoi(e) > 0) rpl = atoi(e); }      // tests: this many, whatever the shape
+    // fp64 diagonal tiles with the first half of their B image in LDS: for models whose scratch images do not stay in L2 (k_var);
+    // GPT_VAR_DIAG_HALF = 0 / 1 forces it off / on (read per call: tests compare both in one process)
+    constexpr bool HALF_OK = std::is_same<T, double>::value;          // (fp32 stages the whole image of a diagonal tile in LDS: DIAG_LDS)
+    bool diag_half = HALF_OK && pl_all.nbi <= 5;
+    if (const char* e = getenv("GPT_VAR_DIAG_HALF")) { if (atoi(e) >= 0) diag_half = HALF_OK && atoi(e) != 0; }
     for (int64_t r0 = 0; r0 == 0 || r0 < rounds; r0 += rpl) {
     VarPlanDev pl = pl_all;
     pl.rnd_begin = r0;
     pl.rnd_end = r0 + rpl < rounds ? r0 + rpl : rounds;
     pl.with_tail = pl.rnd_end >= rounds ? 1 : 0;
-#define GPT_KVAR(NC_, CR_, KT_, DW_) hipLaunchKernelGGL((k_var<T, NC_, CR_, KT_, DW_>), grid, dim3(512), lds, s, p, pl, Xs, Wf, Xq, M, slab, vslab, bscr)
+#define GPT_KVAR(NC_, CR_, KT_, DW_)                                                                                                      \
+    do {                                                                                                                                 \
+        if (diag_half) hipLaunchKernelGGL((k_var<T, NC_, CR_, KT_, DW_, true, HALF_OK>), grid, dim3(512), lds, s, p, pl, Xs, Wf, Xq, M, slab, vslab, bscr); \
+        else hipLaunchKernelGGL((k_var<T, NC_, CR_, KT_, DW_>), grid, dim3(512), lds, s, p, pl, Xs, Wf, Xq, M, slab, vslab, bscr);       \
+    } while (0)
 #define GPT_KVAR1(DW_)                                                  \
         switch (p.ktype) {                                               \
             case KT_MATERN12: GPT_KVAR(1, false, KT_MATERN12, DW_); break; \
             case KT_MATERN32: GPT_KVAR(1, false, KT_MATERN32, DW_); break; \
             case KT_MATERN52: GPT_KVAR(1, false, KT_MATERN52, DW_); break; \
-            default: GPT_KVAR(1, false, KT_RBF, DW_);                    \
+            default: GPT_KVAR(1, false, KT_RBF, DW_); break;             \
         }
     if (ncomp == VAR_NCOMP_DERIV4) {          // D = 4, Jacobian variance alone: dk_0 .. dk_3
         hipLaunchKernelGGL((k_var<T, 4, false, KT_RBF, MAX_D, false>), grid, dim3(512), lds, s, p, pl, Xs, Wf, Xq, M, slab, vslab, bscr);

@@ -1596,3 +1596,55 @@ def test_quarter_tile_cuts_change_no_result_beyond_rounding(monkeypatch):
         _, var, _, Jvar = orc.posterior_all_fast(Xq[idx], X, L, a, c, ls, noise, want_jvar=True)
         assert_parity(outs[0]["var"][idx], var, RTOL, "var vs oracle")
         assert_parity(outs[0]["Jvar"][idx], Jvar, RTOL, "Jvar vs oracle")
+
+
+def test_half_image_diagonal_tiles_change_no_bit(monkeypatch):
+    """Small models (N <= 2560) run k_var's HALF instantiation: the first 64 k-steps of a diagonal tile's B image in LDS
+    (generated there by the generating sweep, copied there by the reload sweeps), the rest from the scratch image.  Every k-step
+    enters the same accumulator in the same order, so the results must be IDENTICAL to the instantiation that reads the whole
+    tile from the scratch image (GPT_VAR_DIAG_HALF=0) — whole rounds, tails, one i-block, the 4-column kernels, the wide layout and the
+    fp64 multi-task model (whose top diagonal tile IS reloaded by the other tasks)."""
+    from gaussian_process_transportation_amd import _lib
+    from oracle import gp_oracle as orc
+    rng = np.random.default_rng(11)
+
+    def both(h, Xq, **flags):
+        outs = []
+        for v in ("1", "0"):
+            monkeypatch.setenv("GPT_VAR_DIAG_HALF", v)
+            outs.append(h.predict_all(Xq, **flags))
+        for k, a in outs[0].items():
+            if a is not None:
+                assert np.array_equal(a, outs[1][k]), (k, flags)
+        return outs[0]
+
+    for N, M in ((300, 700), (1024, 20_000), (2500, 4096), (2500, 17_000), (700, 64)):
+        X, Y, Xq = orc.synthetic_problem(N, M)
+        c, ls, noise, jit = 0.1, np.array([0.1, 0.12, 0.09]), 1e-4, 1e-10
+        h = _lib.Handle(0)
+        h.fit(X, Y, ls, c, noise, jit)
+        o1 = both(h, Xq, mean=True, var=True, J=True)
+        o4 = both(h, Xq, var=True, Jvar=True, dvar=True)
+        both(h, Xq, Jvar=True)
+        idx = np.arange(0, M, max(1, M // 400))
+        L, a = orc.gpr_fit(X, Y, c, ls, noise, jit)
+        _, var, _, Jvar = orc.posterior_all_fast(Xq[idx], X, L, a, c, ls, noise, want_jvar=True)
+        assert_parity(o1["var"][idx], var, RTOL, f"var vs oracle (N={N}, M={M})")
+        assert_parity(o4["Jvar"][idx], Jvar, RTOL, f"Jvar vs oracle (N={N}, M={M})")
+        h.close()
+    # wide layout (D = 6) and Matern
+    X = rng.uniform(0, 1, (900, 6)); Y = np.sin(X[:, :2].sum(1, keepdims=True)); Xq = rng.uniform(0, 1, (3000, 6))
+    h = _lib.Handle(0)
+    h.fit(X, Y, np.full(6, 0.6), 0.5, 1e-3, 1e-10)
+    both(h, Xq, var=True, Jvar=True, dvar=True)
+    h.fit(X, Y, np.full(6, 0.6), 0.5, 1e-3, 1e-10, 2)
+    both(h, Xq, mean=True, var=True)
+    h.close()
+    # fp64 multi-task model: the other tasks reload the top diagonal tile's k-steps
+    Z, T, D = 1100, 3, 3
+    Zp = rng.uniform(0, 1, (Z, D)); A = rng.standard_normal((T, Z, Z)); Sigma = A @ A.transpose(0, 2, 1) / Z + 1e-3 * np.eye(Z)
+    y = rng.standard_normal((T, Z))
+    h = _lib.Handle(0)
+    h.fit_svgp(Zp, y, Sigma, np.full(D, 0.2), np.ones(T), dtype=_lib.GPT_F64)
+    both(h, rng.uniform(0, 1, (9000, D)), mean=True, var=True, J=True, Jvar=True)
+    h.close()
