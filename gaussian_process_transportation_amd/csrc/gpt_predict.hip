@@ -294,6 +294,9 @@ void launch_mean_jac(hipStream_t s, const KernelParams& p, const void* Xs, const
 #ifndef GPT_GEN_DIAG_FREE
 #define GPT_GEN_DIAG_FREE 1      // generating sweeps: diagonal tile barrier-free after its fragments went to the scratch image
 #endif
+#ifndef GPT_GEN_ROLLED
+#define GPT_GEN_ROLLED 1         // openings of a generating sweep: one rolled copy of the generating code (instruction cache)
+#endif
 #ifndef GPT_GEN_BATCH_PROLOGUE
 #define GPT_GEN_BATCH_PROLOGUE 1 // generating sweeps: the first chunk's four source loads in flight together
 #endif
@@ -415,8 +418,13 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
         GPT_VT(0);
         if (flags & VI_FIRST) {
             __syncthreads();                               // LDS (Bs, red, Tt) free / ready
-            // the scratch image is about to be rewritten: drop the L1 lines of it this CU may still hold
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            // The scratch image changes owner: block n's fragments overwrite block n - 1's.  Writers and readers of a workgroup's
+            // image are the waves of THAT workgroup, i.e. of one CU, and its vector L1 is coherent among them (a store through the
+            // L1 updates or drops the line it hits; AMDGPU memory model, non-tgsplit mode: "no special action is required for
+            // coherence between wavefronts in the same work-group") — so workgroup scope is the scope that is needed: ordering, no
+            // cache invalidation.  Until round 4 this was an AGENT-scope acquire (buffer_inv sc1): 20 000 - 35 000 clocks at the
+            // opening of every block, 3 % of the kernel at N = 1024 (ablation 10 in profiles/r04_small_n.txt).
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         } else if (flags & VI_GEN) {
             __syncthreads();                               // nobody may still be reading the part of the image rewritten now
         }
@@ -446,17 +454,35 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
         auto sweep = [&](auto gen_tag) {
             constexpr bool GEN = decltype(gen_tag)::value;
             // this lane's four columns (one per MFMA column tile): scaled query coordinates
+            GPT_VT(11);
             T q[4][3];
             if (GEN && !WIDE) {
+                // twelve loads, no branch between them (a missing coordinate reads coordinate 0 and is scaled by zero): written as
+                // `(d < D) ? Xq[..] : 0` each load sat in its own basic block behind its own s_waitcnt vmcnt(0) — twelve memory
+                // latencies in a row at the opening of every generating sweep (r04_small_n.txt; a prefetch of the next block's
+                // coordinates into LDS by the waves that finish the last diagonal tile early was also built: with the loads batched it
+                // saved 1 500 clocks per block and cost the 3-column kernel spill code in its hot loop — removed)
+                T raw[4][3], qsc[3];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) qsc[d] = (d < D) ? (T)(p.inv_ls[d] * 0.70710678118654752440) : (T)0;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const int64_t col = cb * VAR_COLS + 16 * t + lc;
                     const int64_t m = (NCOMP == 1) ? col : ((NCOMP == 4) ? (col >> 2) : (col / D));
                     const int64_t mm = (m < M) ? m : (M - 1);
+                    const T* qp = Xq + mm * D;
 #pragma unroll
-                    for (int d = 0; d < 3; ++d) q[t][d] = (d < D) ? Xq[mm * D + d] * (T)(p.inv_ls[d] * 0.70710678118654752440) : (T)0;
+                    for (int d = 0; d < 3; ++d) raw[t][d] = qp[d < D ? d : 0];
                 }
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) q[t][d] = raw[t][d] * qsc[d];
             }
+#ifdef GPT_VAR_TRACE
+            if (GEN) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }      // (trace builds: the query coordinates have arrived)
+            GPT_VT(9);
+#endif
             T gx[DW];                                      // coordinates of the source this wave generates next
             T gx_own = (T)0;                               // (wide) and the one a derivative column multiplies by
             v4 bl;                                         // or the fragments it reloads next
@@ -482,7 +508,7 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
             // staged: the four exps of a lane stage by stage (gpt_exp.h kernel_tab4: their latencies overlap — the openings of a
             // sweep, where no MFMA hides them); not staged: one after the other, as few live registers as possible (inside the
             // MFMA loop, where the staged form spills)
-            auto produce_to = [&](auto lds_tag, auto staged_tag, const int buf, const int k4, const bool to_scr = true) {
+            auto produce_to = [&](auto lds_tag, auto staged_tag, const int buf, const int k4, const bool to_scr = true, const bool lds_on = true) {
                 constexpr bool to_lds = decltype(lds_tag)::value;
                 constexpr bool staged = decltype(staged_tag)::value;
                 T* dstl = Bs(buf, k4 % VAR_CH);
@@ -511,7 +537,7 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
                         const int qi = (16 * t + lc) / (CPQ > 1 ? CPQ : 1);
                         b[t] = (NCOMP == 1) ? kv[t] : kv[t] * (cbv + sc_own * (xo - qs[own_d][qi]));
                     }
-                    if (to_lds) *reinterpret_cast<v4*>(dstl) = b;
+                    if (to_lds && lds_on) *reinterpret_cast<v4*>(dstl) = b;
                     if (to_scr) (buni + (size_t)k4 * 64)[lane] = b;
                 } else if (GEN) {
                     const T x0 = gx[0] * RS2, x1 = gx[1] * RS2, x2 = gx[2] * RS2;
@@ -553,7 +579,7 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
                             b[t] = column(t, kv, d0, d1, d2_);
                         }
                     }
-                    if (to_lds) *reinterpret_cast<v4*>(dstl) = b;
+                    if (to_lds && lds_on) *reinterpret_cast<v4*>(dstl) = b;
                     if (GPT_ABL != 8 && to_scr) (buni + (size_t)k4 * 64)[lane] = b;
                 } else {
                     *reinterpret_cast<v4*>(dstl) = bl;
@@ -562,7 +588,8 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
             auto produce = [&](const int buf, const int k4) { produce_to(std::true_type{}, std::false_type{}, buf, k4); };
             // GEN: `cnt` k-steps k4_0 + j * stride generated with their source loads in flight together (load -> wait -> exp ->
             // store one at a time cost 9.5 k cycles per k-step at the opening of a sweep: profiles/r04_small_n.txt)
-            auto generate_batch = [&](auto lds_tag, auto cnt_tag, const int buf, const int k4_0, const int stride, const bool to_scr = true) {
+            auto generate_batch = [&](auto lds_tag, auto cnt_tag, const int buf, const int k4_0, const int stride, const bool to_scr = true,
+                                      const bool lds_on = true) {
                 constexpr int cnt = decltype(cnt_tag)::value;
                 T bx[cnt][DW], bo[cnt];
 #pragma unroll
@@ -572,7 +599,7 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
 #pragma unroll
                     for (int d = 0; d < DW; ++d) gx[d] = bx[j][d];
                     gx_own = bo[j];
-                    produce_to(lds_tag, std::integral_constant<bool, GPT_GEN_STAGED_EXP != 0>{}, buf, k4_0 + j * stride, to_scr);
+                    produce_to(lds_tag, std::integral_constant<bool, GPT_GEN_STAGED_EXP != 0>{}, buf, k4_0 + j * stride, to_scr, lds_on);
                 }
             };
 
@@ -592,13 +619,27 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
             if (GEN && DIAG_FREE && has_diag && GPT_ABL != 3 && !half) {
                 // 128 k-steps, 16 per wave (w, w + 8, ...), VALU only; complete and visible before the barrier below
                 const int kd0 = ib * WT_K4;
+                if (GPT_GEN_ROLLED != 0) {
 #pragma unroll 1
-                for (int j0 = 0; j0 < 16; j0 += 4)
-                    generate_batch(std::false_type{}, std::integral_constant<int, 4>{}, 0, kd0 + w + VAR_SUB * j0, VAR_SUB);
+                    for (int j = 0; j < 16; ++j)
+                        generate_batch(std::false_type{}, std::integral_constant<int, 1>{}, 0, kd0 + w + VAR_SUB * j, VAR_SUB);
+                } else {
+#pragma unroll 1
+                    for (int j0 = 0; j0 < 16; j0 += 4)
+                        generate_batch(std::false_type{}, std::integral_constant<int, 4>{}, 0, kd0 + w + VAR_SUB * j0, VAR_SUB);
+                }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
+            GPT_VT(10);
             if (ch1 > ch0) {                                  // first chunk: wave w fills steps w, w+8, w+16, w+24
-                if (GEN && GPT_GEN_BATCH_PROLOGUE != 0) {
+                if (GEN && GPT_GEN_ROLLED != 0) {
+                    // ONE copy of the generating code, run VAR_SUBS times: the opening of a sweep is straight-line code that runs once
+                    // per block, i.e. from a cold instruction cache — its time followed its LENGTH, not its arithmetic (four k-steps
+                    // unrolled and batched: 40 000 clocks; twenty: 60 000; serial or staged exps: no difference — r04_small_n.txt)
+#pragma unroll 1
+                    for (int j = 0; j < VAR_SUBS; ++j)
+                        generate_batch(std::true_type{}, std::integral_constant<int, 1>{}, ch0 & 1, K0 + j * VAR_SUB + w, VAR_SUB);
+                } else if (GEN && GPT_GEN_BATCH_PROLOGUE != 0) {
                     generate_batch(std::true_type{}, std::integral_constant<int, VAR_SUBS>{}, ch0 & 1, K0 + w, VAR_SUB);
                 } else if (!GEN && El<T>::BATCH_PROLOGUE) {
                     // the four reloads in flight together instead of load -> wait -> write four times (short fp32 sweeps:
@@ -741,7 +782,9 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
                         const int kk = k < limit ? k : limit - 1;
                         b = (bp + (size_t)kk * 64)[lane];
                     };
-                    constexpr int R = GPT_DIAG_RING;                     // 2: the round-1 .. 3 loop, kept for A/B
+                    // (2: the round-1 .. 3 loop, kept for A/B — and for the 3-column kernel, whose generating side keeps more state alive:
+                    // with the deeper ring hipcc reloads a spilled pointer inside the loop, and that reload's wait drains the ring)
+                    constexpr int R = (NCOMP == 3) ? 2 : GPT_DIAG_RING;
                     if constexpr (half) {
                         // Small models (N <= 2560): the B images of an XCD's 32 workgroups (0.5 MB each at N = 1024) do not stay in its
                         // 4 MB of L2, a diagonal tile read straight from the scratch image is 576 wave-steps x 2 KiB from beyond L2, the
@@ -757,13 +800,11 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
                         if constexpr (GEN) {
                             const bool priv = it < n_implicit && pl.ntask == 1;      // the top sweep's own tile: nobody reloads these k-steps
 #pragma unroll 1
-                            for (int j0 = 0; j0 < 8; j0 += 4) {          // k-steps kd0 + w + 8 j, j < 8: below 64 -> LDS
-                                const int k = kd0 + w + VAR_SUB * j0;
-                                generate_batch(std::true_type{}, std::integral_constant<int, 4>{}, (k - kd0) / VAR_CH, k, VAR_SUB, !priv);
+                            for (int j = 0; j < 16; ++j) {               // k-steps kd0 + w + 8 j: below 64 -> LDS (+ scratch unless private), the rest -> scratch
+                                const int k = kd0 + w + VAR_SUB * j;
+                                const bool low = j < 8;
+                                generate_batch(std::true_type{}, std::integral_constant<int, 1>{}, low ? (k - kd0) / VAR_CH : 0, k, VAR_SUB, !(priv && low), low);
                             }
-#pragma unroll 1
-                            for (int j0 = 8; j0 < 16; j0 += 4)           // 64 .. 127 -> scratch image
-                                generate_batch(std::false_type{}, std::integral_constant<int, 4>{}, 0, kd0 + w + VAR_SUB * j0, VAR_SUB);
                             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         } else {
 #pragma unroll

@@ -86,7 +86,8 @@ def main():
                     for w in (0, 3, 4, 7):           # row groups 0, 3, 7, 4
                         s = tr[wi, w, it]
                         d = [int(s[i + 1] - s[i]) if s[i + 1] and s[i] else 0 for i in range(8)]
-                        print(f"    item {it:2d} wave {w}: start +{int(s[0] - t0):8d} | " + " ".join(f"{x:7d}" for x in d) + f" | total {int(s[8] - s[0]):8d}")
+                        op = f"  [opening: to sweep entry +{int(s[11] - s[1])}, queries +{int(s[9] - s[11])}, diag image +{int(s[10] - s[9])}, first fill +{int(s[2] - s[10])}]" if s[9] and s[10] else ""
+                        print(f"    item {it:2d} wave {w}: start +{int(s[0] - t0):8d} | " + " ".join(f"{x:7d}" for x in d) + f" | total {int(s[8] - s[0]):8d}" + op)
                 print("    columns: " + " | ".join(PHASES))
 
 
