@@ -109,13 +109,23 @@ __global__ __launch_bounds__(256) void k_mean_jac(KernelParams p, const T* __res
     if (m0 >= M) return;
     const int D = p.D;
     constexpr T RS2 = (T)0.70710678118654752440;    // coordinates scaled by 1/sqrt(2): k = exp(ln c - |d'|^2)
-    T q[QPW][DW];
+    // (branch-free: written as `(d < D) ? Xq[..] : 0` every load sat in its own basic block behind its own wait — QPW x DW memory
+    // latencies in a row before the first source, as long as the whole contraction at N = 1024; a missing coordinate reads
+    // coordinate 0 and is scaled by zero)
+    T q[QPW][DW], qsc[DW];
+#pragma unroll
+    for (int d = 0; d < DW; ++d) qsc[d] = (d < D) ? (T)(p.inv_ls[d] * 0.70710678118654752440) : (T)0;
 #pragma unroll
     for (int i = 0; i < QPW; ++i) {
         const int64_t m = (m0 + i < M) ? (m0 + i) : (M - 1);
+        const T* qp = Xq + m * D;
 #pragma unroll
-        for (int d = 0; d < DW; ++d) q[i][d] = (d < D) ? Xq[m * D + d] * (T)(p.inv_ls[d] * 0.70710678118654752440) : (T)0;
+        for (int d = 0; d < DW; ++d) q[i][d] = qp[d < D ? d : 0];
     }
+#pragma unroll
+    for (int i = 0; i < QPW; ++i)
+#pragma unroll
+        for (int d = 0; d < DW; ++d) q[i][d] *= qsc[d];
     T acc[QPW][OC][1 + DW];
 #pragma unroll
     for (int i = 0; i < QPW; ++i)
