@@ -92,7 +92,8 @@ template <> struct El<float> {
 // ------------------------------------------------------------------------------------------
 // OC = outputs handled by this pass (1..4): only their partial sums are accumulated.
 // DW = coordinates carried per point: 3 (source rows of 4: the tuned D <= 3 layout) or MAX_D (rows of 8, D = 4..8).
-template <typename T, int QPW, int OC, int KT, int DW>
+// WJ = false: the mean alone (predict without derivative: configs[1]) — no Jacobian sums, a third fewer vector instructions.
+template <typename T, int QPW, int OC, int KT, int DW, bool WJ = true>
 __global__ __launch_bounds__(256) void k_mean_jac(KernelParams p, const T* __restrict__ Xs,
                                                   const T* __restrict__ A4, const T* __restrict__ Xq,
                                                   int64_t M, int o_base, T* __restrict__ mean,
@@ -162,8 +163,10 @@ __global__ __launch_bounds__(256) void k_mean_jac(KernelParams p, const T* __res
             for (int o = 0; o < OC; ++o) {
                 const T t = kv * al[o];
                 acc[i][o][0] += t;
+                if (WJ) {
 #pragma unroll
-                for (int d = 0; d < DW; ++d) acc[i][o][1 + d] += t * df[d];
+                    for (int d = 0; d < DW; ++d) acc[i][o][1 + d] += t * df[d];
+                }
             }
         }
     }
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(256) void k_mean_jac(KernelParams p, const T* __res
 #pragma unroll
         for (int o = 0; o < OC; ++o)
 #pragma unroll
-            for (int e = 0; e < 1 + DW; ++e) {
+            for (int e = 0; e < (WJ ? 1 + DW : 1); ++e) {
                 T v = acc[i][o][e];
 #pragma unroll
                 for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s);
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(256) void k_mean_jac(KernelParams p, const T* __res
             for (int o = 0; o < OC; ++o) {
                 const int oo = o_base + o;
                 if (mean) mean[m * O + oo] = acc[i][o][0];
-                if (J) {
+                if (WJ && J) {
 #pragma unroll
                     for (int d = 0; d < DW; ++d)
                         if (d < D) J[(m * O + oo) * D + d] = acc[i][o][1 + d] * (T)(p.inv_ls[d] * S2);
@@ -212,7 +215,11 @@ static void launch_mean_jac_t(hipStream_t s, const KernelParams& p, const T* Xs,
         const int cnt = (p.O - ob) < 4 ? (p.O - ob) : 4;
         const T* a4 = A4 + (size_t)(ob / 4) * p.NP * 4;
         const dim3 grid((unsigned)blocks);
-#define GPT_MJ(OC_, KT_) hipLaunchKernelGGL((k_mean_jac<T, QPW, OC_, KT_, DW>), grid, dim3(256), 0, s, p, Xs, a4, Xq, M, ob, mean, J)
+#define GPT_MJ(OC_, KT_)                                                                                                          \
+        do {                                                                                                                      \
+            if (J) hipLaunchKernelGGL((k_mean_jac<T, QPW, OC_, KT_, DW, true>), grid, dim3(256), 0, s, p, Xs, a4, Xq, M, ob, mean, J); \
+            else hipLaunchKernelGGL((k_mean_jac<T, QPW, OC_, KT_, DW, false>), grid, dim3(256), 0, s, p, Xs, a4, Xq, M, ob, mean, J);  \
+        } while (0)
 #define GPT_MJ_K(OC_)                                     \
         switch (p.ktype) {                                 \
             case KT_MATERN12: GPT_MJ(OC_, KT_MATERN12); break; \
