@@ -166,7 +166,7 @@ def debug_var_plan(n_columns, n_iblocks, n_tasks, n_workgroups, order=-1):
     check(lib.gpt_debug_var_plan(n_columns, n_iblocks, n_tasks, n_workgroups, order, counts, item_begin.ctypes.data_as(ip),
                                  items.ctypes.data_as(ip), fin.ctypes.data_as(ip), splits.ctypes.data_as(ip)))
     return {"n_items": counts[0], "n_splits": counts[1], "n_slots": counts[2], "n_vslots": counts[3], "ncb": counts[4],
-            "nfull": counts[5], "order": counts[7], "cohorts": bool(counts[8]), "cohort_s": counts[9], "cohort_f": counts[10],
+            "nfull": counts[5], "order": counts[7], "cohorts": bool(counts[8]), "cohort_s": counts[9], "cohort_f": counts[10], "cut_diag": bool(counts[11]),
             "item_begin": item_begin, "items": items[:counts[0]],
             "fin": fin[:counts[6]], "splits": splits[:counts[1]]}
 

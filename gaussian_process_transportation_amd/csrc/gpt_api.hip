@@ -1046,7 +1046,7 @@ int gpt_debug_var_plan(int64_t n_columns, int n_iblocks, int n_tasks, int n_work
     const VarPlanHost pl = build_var_plan(n_columns, n_iblocks, n_tasks, n_workgroups, order);
     counts[0] = (int64_t)pl.items.size(); counts[1] = (int64_t)pl.splits.size(); counts[2] = pl.n_slots; counts[3] = pl.n_vslots;
     counts[4] = pl.d.ncb; counts[5] = pl.d.nfull; counts[6] = (int64_t)pl.fin.size() / 2; counts[7] = pl.order;
-    counts[8] = pl.cohorts; counts[9] = pl.cohort_s; counts[10] = pl.cohort_f; counts[11] = 0;
+    counts[8] = pl.cohorts; counts[9] = pl.cohort_s; counts[10] = pl.cohort_f; counts[11] = pl.cut_diag;
     if (item_begin) memcpy(item_begin, pl.item_begin.data(), pl.item_begin.size() * sizeof(int));
     if (items && !pl.items.empty()) memcpy(items, pl.items.data(), pl.items.size() * sizeof(VarItem));
     if (fin && !pl.fin.empty()) memcpy(fin, pl.fin.data(), pl.fin.size() * sizeof(int));

@@ -6,7 +6,7 @@
 // columns, 64 per column block.  A *sweep* is (column block cb, task, i-block ib, k range [k_lo, k_hi)) counted in QUARTER
 // tiles (VAR_KQ per tile: 32 k4-steps, one LDS chunk of the kernel), k_hi <= 4 (ib + 1); a whole sweep has k_lo = 0,
 // k_hi = 4 (ib + 1) and its 512 x 64 result is folded straight into the per-column sums of squares.  The diagonal tile
-// [4 ib, 4 ib + 4) is never divided.
+// [4 ib, 4 ib + 4) is divided only where a workgroup's share of the list is small against it (cut_diag below).
 //
 //   * Rounds: while at least P (= workgroups = CUs) column blocks are left, workgroup p takes block r P + p whole, all
 //     tasks, longest sweep first — every workgroup then walks the same tiles of A at the same time, which is what
@@ -41,10 +41,12 @@ constexpr int VAR_TILE_COST = 128;     // k4-steps of a full tile
 constexpr int VAR_KQ = 4;              // item k ranges count quarter tiles
 constexpr int VAR_Q_COST = VAR_TILE_COST / VAR_KQ;     // 32 k4-steps = one LDS chunk of k_var (both element types)
 constexpr int VAR_SWEEP_OVERHEAD = 6;  // fixed cost of a sweep in k4-steps (first fill, accumulator fold)
+constexpr int VAR_SPLIT_SLOTS = 8;     // slab slots of a cut sweep: k_var_combine reduces each of the 8 row groups in a workgroup of its own
+constexpr int VAR_DIAG_SHARE = 4 * VAR_TILE_COST;      // the diagonal tile may be cut when a workgroup's share of the list is below this
 
 struct VarItem {
     int cb, task, ib;     // column block, task, i-block
-    int k_lo, k_hi;       // quarter tiles [k_lo, k_hi), k_hi <= 4 (ib + 1); the diagonal tile [4 ib, 4 ib + 4) whole or not at all
+    int k_lo, k_hi;       // quarter tiles [k_lo, k_hi), k_hi <= 4 (ib + 1)
     int flags;            // VI_*
     int slot;             // >= 0: after this item the running column sums go to slab slot `slot`
     int vslot;            // >= 0: partial product, stored to vslab slot `vslot` instead of being folded
@@ -53,7 +55,7 @@ enum { VI_GEN = 1,        // B fragments of [k_lo, k_hi) are generated (and copi
        VI_FIRST = 2,      // first item of this workgroup for this column block: the scratch image changes owner
        VI_ZERO = 4 };     // the running column sums start from zero
 
-struct VarSplit { int v_begin, v_end, slot; };   // combine vslab slots [v_begin, v_end) into slab slot `slot`
+struct VarSplit { int v_begin, v_end, slot; };   // combine vslab slots [v_begin, v_end) into slab slots [slot, slot + VAR_SPLIT_SLOTS)
 
 // Passed by value to the kernels.
 struct VarPlanDev {
@@ -81,16 +83,31 @@ struct VarPlanHost {
     int64_t n_slots = 0;        // slab slots
     int64_t n_vslots = 0;       // vslab slots (partial products)
     int order = 0;              // 0 block-major, 1 sweep-major
+    int cut_diag = 0;           // the list was cut with the diagonal tiles divisible (small shares)
     int cohorts = 0, cohort_s = 0, cohort_f = 0;   // the tail was split into cohorts: long sweeps ib >= s (+ the last f tiles of s-1) whole
 };
 
+// Quarters [qa, qb) of a diagonal tile, in the cost unit of the full tiles (k4-steps of a SIMD that holds two waves).  Row group g
+// has 16 (g + 1) k4-steps in the tile and shares its SIMD with group 7 - g: whole, every SIMD has 144 wave-steps (72); a
+// part has what the two groups have inside [32 qa, 32 qb), and a wave that is alone on its SIMD runs at 0.6 of the
+// pair's time per step, not 0.5 (1 250 against 2 x 1 024 clocks: profiles/r04_small_n.txt).
+inline int var_diag_cost(int qa, int qb) {
+    if (qa == 0 && qb == VAR_KQ) return VAR_DIAG_COST;
+    int worst = 0;
+    for (int g = 0; g < 4; ++g) {
+        auto steps = [&](int gg) { const int hi = std::min(16 * (gg + 1), VAR_Q_COST * qb); return std::max(hi - VAR_Q_COST * qa, 0); };
+        const int a = steps(g), b = steps(7 - g);
+        worst = std::max(worst, std::max((a + b) / 2, (6 * std::max(a, b) + 9) / 10));
+    }
+    return worst;
+}
 // k_lo, k_hi in quarter tiles
 inline int var_sweep_cost(int ib, int k_lo, int k_hi) {
     const int diag_lo = VAR_KQ * ib;
     const int full_end = k_hi < diag_lo ? k_hi : diag_lo;
     int c = VAR_SWEEP_OVERHEAD;
     if (full_end > k_lo) c += VAR_Q_COST * (full_end - k_lo);
-    if (k_hi == diag_lo + VAR_KQ) c += VAR_DIAG_COST;
+    if (k_hi > diag_lo) c += var_diag_cost((k_lo > diag_lo ? k_lo : diag_lo) - diag_lo, k_hi - diag_lo);
     return c;
 }
 inline int var_whole_sweep_cost(int ib) { return var_sweep_cost(ib, 0, VAR_KQ * (ib + 1)); }
@@ -132,8 +149,15 @@ inline VarPlanHost build_var_plan(int64_t ncols, int nbi, int ntask, int P, int 
     constexpr int TOL = VAR_Q_COST / 2;
     // diagnostic: GPT_VAR_CUT_TILES=1 cuts at whole tiles (the granularity of rounds 2 and 3) for A/B runs
     const int gran = [] { const char* e = getenv("GPT_VAR_CUT_TILES"); return (e && atoi(e) != 0) ? VAR_KQ : 1; }();
+    // diagnostic: GPT_VAR_CUT_DIAG=0 / 1 never / always allows cuts inside a diagonal tile
+    const int cut_diag_env = [] { const char* e = getenv("GPT_VAR_CUT_DIAG"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
     // lays `sw` end to end over the workgroups [p_begin, p_begin + Pn) in Pn ranges of equal cost; U = total cost to share
     auto cut_range = [&](const std::vector<Sweep>& sw, const int p_begin, const int Pn, const int64_t U) -> int64_t {
+        // A diagonal tile is 72 units whole and 32 + 32 + 20 + 20 in quarters: cut only where a whole one is a large part of
+        // a workgroup's share — the 14-block tail of configs[1] (N = 1024: 42 tiles for 256 workgroups) took as long as its
+        // diagonal tiles, 0.085 ms of a 0.98 ms launch; the lists of the large models (shares of thousands of units) stay as they were.
+        const bool cut_diag = cut_diag_env >= 0 ? cut_diag_env != 0 : U / Pn < VAR_DIAG_SHARE;
+        h.cut_diag = cut_diag ? 1 : 0;
         int p = 0;
         int64_t cum = 0;
         auto boundary = [&](int q) { return U / Pn * (q + 1) + (U % Pn) * (q + 1) / Pn; };
@@ -149,13 +173,13 @@ inline VarPlanHost build_var_plan(int64_t ncols, int nbi, int ntask, int P, int 
                 int take = kend - k;
                 if (p < Pn - 1 && rem > room + TOL) {
                     // quarter tiles that fit into what is left of this workgroup's share (full tiles come first, the diagonal
-                    // tile last and whole); something is left for the next workgroup
-                    int64_t nt = (room - VAR_SWEEP_OVERHEAD + TOL) / VAR_Q_COST;
-                    const int max_take = (kend > diag_lo ? diag_lo : kend - 1) - k;
-                    if (nt > max_take) nt = max_take;
-                    nt = nt / gran * gran;
+                    // tile last — whole, unless the shares are small against it: cut_diag); something is left for the next workgroup
+                    const int max_take = (cut_diag ? kend - 1 : (kend > diag_lo ? diag_lo : kend - 1)) - k;
+                    int nt = 0;
+                    while (nt < max_take && var_sweep_cost(s.ib, k, k + nt + 1) <= room + TOL) ++nt;
+                    if (!cut_diag || k + nt <= diag_lo) nt = nt / gran * gran;
                     if (nt < 1) { ++p; continue; }                       // nothing fits: close this workgroup
-                    take = (int)nt;
+                    take = nt;
                 }
                 VarItem it{(int)d.nfull + s.cbt, s.task, s.ib, k, k + take, 0, -1, -1};
                 parts.emplace_back(p_begin + p, (int)wg[p_begin + p].size());
@@ -181,15 +205,17 @@ inline VarPlanHost build_var_plan(int64_t ncols, int nbi, int ntask, int P, int 
         h.n_vslots = 0;
     };
     // Every part of a cut sweep pays the fixed sweep overhead again, so the total to share is only known once the cuts
-    // are: the cut is repeated with the total the previous pass produced (settles after one repetition).
+    // are — and a diagonal tile costs more in parts than whole: the cut is repeated with the total the previous pass produced
+    // until a pass stays within the total it was given (the shares are then upper bounds; a pass that exceeds its total leaves
+    // the excess to the last workgroup).
     auto cut_settled = [&](std::vector<Sweep>& sw, const int p_begin, const int Pn, auto&& before_each) {
         int64_t U = 0;
         for (const Sweep& x : sw) U += var_sweep_cost(x.ib, 0, x.k1 >= 0 ? x.k1 : VAR_KQ * (x.ib + 1));
-        for (int rep = 0; rep < 4; ++rep) {
+        for (int rep = 0; rep < 8; ++rep) {
             reset();
             before_each();                       // (may set the k0 / pre_* fields of sw: the U of the first pass is then an over-estimate, corrected by the repetition)
             const int64_t U2 = cut_range(sw, p_begin, Pn, U);
-            if (U2 == U) break;
+            if (U2 <= U && (rep > 0 || U2 == U)) break;
             U = U2;
         }
     };
@@ -293,7 +319,7 @@ inline VarPlanHost build_var_plan(int64_t ncols, int nbi, int ntask, int P, int 
     for (size_t ct = 0; ct < contrib.size(); ++ct) {
         h.fin[2 * ct] = (int)h.n_slots;
         for (const Contribution& c : contrib[ct]) {
-            if (c.split) h.splits[c.ref].slot = (int)h.n_slots++;
+            if (c.split) { h.splits[c.ref].slot = (int)h.n_slots; h.n_slots += VAR_SPLIT_SLOTS; }
             else h.items[c.ref].slot = (int)h.n_slots++;
         }
         h.fin[2 * ct + 1] = (int)h.n_slots;

@@ -622,7 +622,10 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
 
             const size_t S_ib = (size_t)task * pl.tiles_per_task * WT_K4 + (size_t)64 * ib * (ib + 1);   // stream index of k4-step 0 of this i-block
             static_assert(VAR_CH == VAR_Q_COST && WT_K4 == VAR_KQ * VAR_CH, "an item's k range counts LDS chunks (quarter tiles)");
-            const bool has_diag = (k_hi == VAR_KQ * (ib + 1));                 // (the diagonal tile is never divided: gpt_plan.h)
+            // the item's part of the diagonal tile: k4-steps [d_lo, d_hi) of it — the whole tile (0, 128) everywhere except in the lists
+            // of small launches, where the plan may cut it at quarters (gpt_plan.h: cut_diag)
+            const bool has_diag = k_hi > VAR_KQ * ib;
+            const int d_lo = (k_lo > VAR_KQ * ib ? k_lo - VAR_KQ * ib : 0) * VAR_CH, d_hi = (k_hi - VAR_KQ * ib) * VAR_CH;
             const int K0 = k_lo * VAR_CH;                                      // first k4-step of this item
             // The diagonal tile (where wave g only has 16 (g + 1) steps of work) runs OUT of the lock-step LDS pipeline: see
             // below.  A generating sweep first puts that tile's fragments into the scratch image (GEN_DIAG_FREE; until round 4 it
@@ -634,15 +637,15 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
             // the first 64 k-steps of a diagonal tile's B image go through LDS — see the tile below
             constexpr bool half = HALF && !El<T>::DIAG_LDS;
             if (GEN && DIAG_FREE && has_diag && GPT_ABL != 3 && !half) {
-                // 128 k-steps, 16 per wave (w, w + 8, ...), VALU only; complete and visible before the barrier below
+                // 128 k-steps (of a whole tile), 16 per wave (w, w + 8, ...), VALU only; complete and visible before the barrier below
                 const int kd0 = ib * WT_K4;
                 if (GPT_GEN_ROLLED != 0) {
 #pragma unroll 1
-                    for (int j = 0; j < 16; ++j)
+                    for (int j = d_lo / VAR_SUB; j < d_hi / VAR_SUB; ++j)
                         generate_batch(std::false_type{}, std::integral_constant<int, 1>{}, 0, kd0 + w + VAR_SUB * j, VAR_SUB);
                 } else {
 #pragma unroll 1
-                    for (int j0 = 0; j0 < 16; j0 += 4)
+                    for (int j0 = d_lo / VAR_SUB; j0 < d_hi / VAR_SUB; j0 += 4)
                         generate_batch(std::false_type{}, std::integral_constant<int, 4>{}, 0, kd0 + w + VAR_SUB * j0, VAR_SUB);
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -751,7 +754,8 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
                 // lock-step, so the waves with g and 7 - g that share a SIMD add up to the same work on every SIMD: the tile
                 // costs 0.56 of a full one instead of the 0.75 it costs inside the lock-step pipeline.
                 const int kd0 = ib * WT_K4;                              // first k-step of the diagonal tile
-                const int limit = (GPT_ABL == 6) ? 72 : 16 * (g + 1);    // multiple of 16 (ablation 6: every wave the average, 72: what an even split inside a SIMD would cost)
+                const int lim_g = (GPT_ABL == 6) ? 72 : 16 * (g + 1);    // multiple of 16 (ablation 6: every wave the average, 72: what an even split inside a SIMD would cost)
+                const int limit = lim_g < d_hi ? lim_g : d_hi;           // this wave's steps: [d_lo, limit), none if limit <= d_lo
                 const avec* ap = wuni + (S_ib + kd0) * A_STEP;
                 const v4* bp = buni + (size_t)kd0 * 64;
                 auto ldA = [&](AF& a, const int k) {
@@ -768,9 +772,10 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
                     constexpr int DP = El<T>::PF;
                     AF a[DP];
 #pragma unroll
-                    for (int i = 0; i < DP; ++i) ldA(a[i], i);
+                    for (int i = 0; i < DP; ++i) ldA(a[i], d_lo + i);
 #pragma unroll
                     for (int half = 0; half < 2; ++half) {
+                        if (d_lo >= 64 * (half + 1) || d_hi <= 64 * half) continue;      // (workgroup-uniform: not a k-step of this item)
                         v4 r[8];
 #pragma unroll
                         for (int j = 0; j < 8; ++j) r[j] = (bp + (size_t)(w + 8 * (8 * half + j)) * 64)[lane];
@@ -778,8 +783,8 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
                         for (int j = 0; j < 8; ++j) img[(w + 8 * (8 * half + j)) * 64 + lane] = r[j];
                     }
                     __syncthreads();
-                    v4 b_nxt = img[lane];
-                    for (int k4 = 0; k4 < limit; k4 += DP) {
+                    v4 b_nxt = img[d_lo * 64 + lane];
+                    for (int k4 = d_lo; k4 < limit; k4 += DP) {
 #pragma unroll
                         for (int i = 0; i < DP; ++i) {
                             const v4 b = b_nxt;
@@ -817,7 +822,7 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
                         if constexpr (GEN) {
                             const bool priv = it < n_implicit && pl.ntask == 1;      // the top sweep's own tile: nobody reloads these k-steps
 #pragma unroll 1
-                            for (int j = 0; j < 16; ++j) {               // k-steps kd0 + w + 8 j: below 64 -> LDS (+ scratch unless private), the rest -> scratch
+                            for (int j = d_lo / VAR_SUB; j < d_hi / VAR_SUB; ++j) {      // k-steps kd0 + w + 8 j: below 64 -> LDS (+ scratch unless private), the rest -> scratch
                                 const int k = kd0 + w + VAR_SUB * j;
                                 const bool low = j < 8;
                                 generate_batch(std::true_type{}, std::integral_constant<int, 1>{}, low ? (k - kd0) / VAR_CH : 0, k, VAR_SUB, !(priv && low), low);
@@ -826,6 +831,7 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
                         } else {
 #pragma unroll
                             for (int hh = 0; hh < 2; ++hh) {
+                                if (d_lo >= 32 * (hh + 1) || d_hi <= 32 * hh) continue;      // (workgroup-uniform)
                                 v4 r[4];
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) r[j] = (bp + (size_t)(w + 8 * (4 * hh + j)) * 64)[lane];
@@ -837,10 +843,11 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
                         AF a[R];
                         v4 b[R];
 #pragma unroll
-                        for (int i = 0; i < R; ++i) ldA(a[i], i);
+                        for (int i = 0; i < R; ++i) ldA(a[i], d_lo + i);
                         const int l1 = limit < 64 ? limit : 64;
-                        v4 b_nxt = img[lane];
-                        for (int k4 = 0; k4 < l1; k4 += R) {
+                        const int p2 = d_lo > 64 ? d_lo : 64;             // first step that comes from the scratch image
+                        v4 b_nxt = img[(d_lo < 64 ? d_lo : 63) * 64 + lane];
+                        for (int k4 = d_lo; k4 < l1; k4 += R) {
 #pragma unroll
                             for (int i = 0; i < R; ++i) {
                                 const v4 bb = b_nxt;
@@ -852,11 +859,11 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
                                 ldA(a[i], k4 + i + R);
                             }
                         }
-                        if (limit > 64) {
+                        if (limit > p2) {
 #pragma unroll
-                            for (int i = 0; i < R; ++i) ldB(b[i], 64 + i);
+                            for (int i = 0; i < R; ++i) ldB(b[i], p2 + i);
                         }
-                        for (int k4 = 64; k4 < limit; k4 += R) {
+                        for (int k4 = p2; k4 < limit; k4 += R) {
 #pragma unroll
                             for (int i = 0; i < R; ++i) {
                                 __builtin_amdgcn_sched_barrier(0);
@@ -869,8 +876,8 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
                     } else if constexpr (R == 2) {
                         AF a0, a1;
                         v4 b0, b1;
-                        ldA(a0, 0); ldA(a1, 1); ldB(b0, 0);
-                        for (int k4 = 0; k4 < limit; k4 += 2) {
+                        ldA(a0, d_lo); ldA(a1, d_lo + 1); ldB(b0, d_lo);
+                        for (int k4 = d_lo; k4 < limit; k4 += 2) {
                             ldB(b1, k4 + 1);
                             __builtin_amdgcn_sched_barrier(0);
                             El<T>::mfma16(acc, a0, b0);
@@ -888,8 +895,8 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
                         AF a[R];
                         v4 b[R];
 #pragma unroll
-                        for (int i = 0; i < R; ++i) { ldA(a[i], i); ldB(b[i], i); }
-                        for (int k4 = 0; k4 < limit; k4 += R) {           // limit is a multiple of 16, R divides 16
+                        for (int i = 0; i < R; ++i) { ldA(a[i], d_lo + i); ldB(b[i], d_lo + i); }
+                        for (int k4 = d_lo; k4 < limit; k4 += R) {        // d_lo and limit are multiples of 16, R divides 16
 #pragma unroll
                             for (int i = 0; i < R; ++i) {
                                 __builtin_amdgcn_sched_barrier(0);
@@ -973,33 +980,34 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
 }
 
 // A sweep the work split cut along k: add its parts' partial products in part order, then square / reduce as the
-// kernel's own epilogue does.  One workgroup per cut sweep, same thread -> element map as k_var.
+// kernel's own epilogue does.  VAR_SPLIT_SLOTS (8) workgroups per cut sweep, one per row group (= wave of k_var), each with a slab
+// slot of its own; wave r of the workgroup takes the group's row tile r, same lane -> element map as k_var.  (One workgroup
+// per cut sweep until round 4: 14 workgroups x 1.3 MB at configs[1], 18 us at the rate of 14 CUs.)
 template <typename T, bool CROSS, int CPQ = 4>
-__global__ __launch_bounds__(512) void k_var_combine(VarPlanDev pl, const T* __restrict__ vslab, T* __restrict__ slab) {
+__global__ __launch_bounds__(256) void k_var_combine(VarPlanDev pl, const T* __restrict__ vslab, T* __restrict__ slab) {
     typedef typename El<T>::v4 v4;
-    __shared__ T red[2][8][VAR_COLS];
-    const VarSplit sp = pl.splits[blockIdx.x];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __shared__ T red[2][4][VAR_COLS];
+    const VarSplit sp = pl.splits[blockIdx.x / VAR_SPLIT_SLOTS];
+    const int grp = blockIdx.x % VAR_SPLIT_SLOTS;
+    const int lane = threadIdx.x & 63, r = threadIdx.x >> 6;
     const int lc = lane & 15, lk = lane >> 4;
-    v4 acc[16];
+    v4 acc[4];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = v4{0, 0, 0, 0};
+    for (int t = 0; t < 4; ++t) acc[t] = v4{0, 0, 0, 0};
     for (int v = sp.v_begin; v < sp.v_end; ++v) {
-        const v4* src = reinterpret_cast<const v4*>(vslab) + ((size_t)v * 8 + w) * (16 * 64) + lane;
+        const v4* src = reinterpret_cast<const v4*>(vslab) + ((size_t)v * 8 + grp) * (16 * 64) + lane;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] += src[i * 64];
+        for (int t = 0; t < 4; ++t) acc[t] += src[(r * 4 + t) * 64];
     }
     T ssq[4] = {0, 0, 0, 0}, crs[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const T v = acc[r * 4 + t][e];
-                ssq[t] += v * v;
-                if (CROSS) crs[t] += v * __shfl(v, lane & ~(CPQ - 1));
-            }
+        for (int e = 0; e < 4; ++e) {
+            const T v = acc[t][e];
+            ssq[t] += v * v;
+            if (CROSS) crs[t] += v * __shfl(v, lane & ~(CPQ - 1));
+        }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         ssq[t] += __shfl_xor(ssq[t], 16); ssq[t] += __shfl_xor(ssq[t], 32);
@@ -1008,8 +1016,8 @@ __global__ __launch_bounds__(512) void k_var_combine(VarPlanDev pl, const T* __r
     if (lk == 0) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            red[0][w][16 * t + lc] = ssq[t];
-            red[1][w][16 * t + lc] = CROSS ? crs[t] : (T)0;
+            red[0][r][16 * t + lc] = ssq[t];
+            red[1][r][16 * t + lc] = CROSS ? crs[t] : (T)0;
         }
     }
     __syncthreads();
@@ -1017,8 +1025,8 @@ __global__ __launch_bounds__(512) void k_var_combine(VarPlanDev pl, const T* __r
         const int which = threadIdx.x >> 6, cl = threadIdx.x & 63;
         T v = (T)0;
 #pragma unroll
-        for (int ww = 0; ww < 8; ++ww) v += red[which][ww][cl];
-        slab[(size_t)sp.slot * VAR_SLOT + threadIdx.x] = v;
+        for (int rr = 0; rr < 4; ++rr) v += red[which][rr][cl];
+        slab[((size_t)sp.slot + grp) * VAR_SLOT + threadIdx.x] = v;
     }
 }
 
@@ -1107,7 +1115,7 @@ static void launch_var_t(hipStream_t s, const KernelParams& p, const VarWorkspac
     T* slab = static_cast<T*>(ws.slab);
     T* vslab = static_cast<T*>(ws.vslab);
     T* bscr = static_cast<T*>(ws.bscratch);
-    const dim3 grid((unsigned)pl_all.P), fgrid((unsigned)pl_all.ncb), cgrid((unsigned)pl_all.n_splits);
+    const dim3 grid((unsigned)pl_all.P), fgrid((unsigned)pl_all.ncb), cgrid((unsigned)pl_all.n_splits * VAR_SPLIT_SLOTS);
     const bool wide = p.D > 3;
     const bool cross = ncomp >= 4 && dvar != nullptr;
     // The persistent workgroups are not synchronised between rounds and drift apart; once they are further apart than a W
@@ -1169,10 +1177,10 @@ static void launch_var_t(hipStream_t s, const KernelParams& p, const VarWorkspac
 #undef GPT_KVAR
     const VarPlanDev& pl = pl_all;
     if (pl.n_splits > 0) {
-        if (!cross) hipLaunchKernelGGL((k_var_combine<T, false>), cgrid, dim3(512), 0, s, pl, vslab, slab);
-        else if (ncomp == 4) hipLaunchKernelGGL((k_var_combine<T, true, 4>), cgrid, dim3(512), 0, s, pl, vslab, slab);
-        else if (ncomp == 8) hipLaunchKernelGGL((k_var_combine<T, true, 8>), cgrid, dim3(512), 0, s, pl, vslab, slab);
-        else hipLaunchKernelGGL((k_var_combine<T, true, 16>), cgrid, dim3(512), 0, s, pl, vslab, slab);
+        if (!cross) hipLaunchKernelGGL((k_var_combine<T, false>), cgrid, dim3(256), 0, s, pl, vslab, slab);
+        else if (ncomp == 4) hipLaunchKernelGGL((k_var_combine<T, true, 4>), cgrid, dim3(256), 0, s, pl, vslab, slab);
+        else if (ncomp == 8) hipLaunchKernelGGL((k_var_combine<T, true, 8>), cgrid, dim3(256), 0, s, pl, vslab, slab);
+        else hipLaunchKernelGGL((k_var_combine<T, true, 16>), cgrid, dim3(256), 0, s, pl, vslab, slab);
     }
     switch (ncomp) {
         case VAR_NCOMP_DERIV4: hipLaunchKernelGGL((k_var_finalize<T, 4, false>), fgrid, dim3(64), 0, s, p, pl, slab, M, hdr, var, Jvar, dvar); break;

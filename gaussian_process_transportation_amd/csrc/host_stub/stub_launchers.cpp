@@ -90,7 +90,7 @@ void launch_var(hipStream_t, const KernelParams& p, const VarWorkspace& ws, cons
     for (int i = 0; i < pl.d.n_splits; ++i) {
         const VarSplit sp = pl.d.splits[i];
         touch_r(static_cast<unsigned char*>(ws.vslab) + (size_t)sp.v_begin * VAR_VSLOT * e, (size_t)(sp.v_end - sp.v_begin) * VAR_VSLOT * e);
-        touch_w(static_cast<unsigned char*>(ws.slab) + (size_t)sp.slot * VAR_SLOT * e, (size_t)VAR_SLOT * e);
+        touch_w(static_cast<unsigned char*>(ws.slab) + (size_t)sp.slot * VAR_SLOT * e, (size_t)VAR_SPLIT_SLOTS * VAR_SLOT * e);
     }
     for (int64_t c = 0; c < pl.d.ncb - pl.d.nfull; ++c)
         for (int t = 0; t < p.ntask; ++t) {

@@ -208,7 +208,8 @@ int gpt_predict_timings(gpt_handle* h, double* ms_out);
  * columns over n_iblocks 512-row blocks x n_tasks tasks on n_workgroups workgroups (csrc/gpt_plan.h).
  * order: -1 automatic, 0 block-major, 1 sweep-major.  counts[12] = {items, cut sweeps, slab slots, partial-product
  * slots, column blocks, blocks in whole rounds, tail (block, task) pairs, order used, cohort plan used (0 / 1), its first whole
- * i-block s, tiles f of sweep s - 1 taken with the long sweeps, 0}; item k ranges count quarter tiles; the arrays may be NULL (first
+ * i-block s, tiles f of sweep s - 1 taken with the long sweeps, diagonal tiles divisible in this list (0 / 1)}; item k ranges
+ * count quarter tiles; a cut sweep owns 8 consecutive slab slots from splits[.][2]; the arrays may be NULL (first
  * call) or hold item_begin[n_workgroups + 1], items[counts[0]][8], fin[counts[6]][2], splits[counts[1]][3]. */
 int gpt_debug_var_plan(int64_t n_columns, int n_iblocks, int n_tasks, int n_workgroups, int order, int64_t* counts,
                        int* item_begin, int* items, int* fin, int* splits);

@@ -273,11 +273,23 @@ def test_bench_launcher_does_not_touch_the_gpu_stack():
 VI_GEN, VI_FIRST, VI_ZERO = 1, 2, 4
 
 
-def _check_var_plan(cols, nbi, nt, P, order):
-    """Replays the item lists of csrc/gpt_plan.h the way k_var executes them and checks what the kernel relies on."""
+def _diag_cost(qa, qb):
+    """gpt_plan.h var_diag_cost: quarters [qa, qb) of a diagonal tile — row groups g and 7 - g share a SIMD, group g has 16 (g + 1) steps."""
+    if (qa, qb) == (0, 4):
+        return 72
+    steps = lambda g: max(min(16 * (g + 1), 32 * qb) - 32 * qa, 0)
+    return max(max((steps(g) + steps(7 - g)) // 2, (6 * max(steps(g), steps(7 - g)) + 9) // 10) for g in range(4))
+
+
+def _check_var_plan(cols, nbi, nt, P, order, cut_diag=None):
+    """Replays the item lists of csrc/gpt_plan.h the way k_var executes them and checks what the kernel relies on.
+    cut_diag: None = the plan decides whether a diagonal tile may be divided (only where a workgroup's share is below 4 tiles)."""
     from collections import defaultdict
     from gaussian_process_transportation_amd import _lib
     pl = _lib.debug_var_plan(cols, nbi, nt, P, order)
+    if cut_diag is not None:
+        assert pl["cut_diag"] == cut_diag
+    cut_diag = pl["cut_diag"]
     ncb, nfull = pl["ncb"], pl["nfull"]
     assert ncb == -(-cols // 64) and nfull == ncb // P * P
     ncb_t = ncb - nfull
@@ -292,7 +304,8 @@ def _check_var_plan(cols, nbi, nt, P, order):
         cur_cb, generated, running = None, set(), None
         for cb, task, ib, k_lo, k_hi, flags, slot, vslot in pl["items"][ib_[p]:ib_[p + 1]]:
             assert nfull <= cb < ncb and 0 <= task < nt and 0 <= ib < nbi and 0 <= k_lo < k_hi <= KQ * (ib + 1)
-            assert k_hi <= KQ * ib or (k_hi == KQ * (ib + 1) and k_lo <= KQ * ib), "the diagonal tile must not be divided"
+            if not cut_diag:
+                assert k_hi <= KQ * ib or (k_hi == KQ * (ib + 1) and k_lo <= KQ * ib), "the diagonal tile must not be divided here"
             if cb != cur_cb:
                 assert flags & VI_FIRST, "a new column block must drop the previous scratch image"
                 cur_cb, generated = cb, set()
@@ -302,7 +315,7 @@ def _check_var_plan(cols, nbi, nt, P, order):
             else:
                 assert tiles <= generated, "reload of B fragments this workgroup never generated for this block"
             cover[cb - nfull, task, ib, k_lo:k_hi] += 1
-            cost[p] += 32 * max(min(k_hi, KQ * ib) - k_lo, 0) + (72 if k_hi == KQ * (ib + 1) else 0)
+            cost[p] += 32 * max(min(k_hi, KQ * ib) - k_lo, 0) + (_diag_cost(max(k_lo - KQ * ib, 0), k_hi - KQ * ib) if k_hi > KQ * ib else 0)
             if vslot >= 0:
                 assert slot < 0 and vslot not in vslot_part
                 vslot_part[vslot] = (cb, task, ib, k_lo, k_hi)
@@ -328,8 +341,9 @@ def _check_var_plan(cols, nbi, nt, P, order):
         assert len(parts) >= 2 and len({pp[:3] for pp in parts}) == 1
         assert parts[0][3] == 0 and parts[-1][4] == KQ * (parts[0][2] + 1)
         assert all(a[4] == b[3] for a, b in zip(parts, parts[1:])), "parts of a cut sweep must tile its k range in order"
-        assert slot not in slot_sweeps
-        slot_sweeps[slot] = [parts[0][:3]]
+        for g in range(8):                # one slab slot per row group (gpt_plan.h VAR_SPLIT_SLOTS), k_var_finalize adds them
+            assert slot + g not in slot_sweeps
+            slot_sweeps[slot + g] = [parts[0][:3]] if g == 0 else []
     assert sorted(slot_sweeps) == list(range(nfull * nt, pl["n_slots"]))
     assert len(pl["fin"]) == ncb_t * nt
     for e, (b, en) in enumerate(pl["fin"]):
@@ -389,6 +403,27 @@ def test_variance_work_plan_cohorts_keep_the_long_sweeps_whole():
         rest = pl["items"][ib_[ncb]:]
         assert len(rest) and max(int(it[2]) for it in rest) == s - 1
         _check_var_plan(cols, nbi, 1, 256, -1)
+
+
+def test_variance_work_plan_divides_diagonal_tiles_only_for_small_shares(monkeypatch):
+    """configs[1] (N = 1024, M = 50 000): three rounds + 14 blocks = 42 tiles, 28 of them diagonal, for 256 workgroups.  With the diagonal
+    tile indivisible the tail took as long as one (78 units + its opening); cut at quarters no workgroup gets more than 46.  Lists whose
+    shares are several tiles (every large model) keep their diagonal tiles whole — and their plans as they were measured."""
+    pl, cost = _check_var_plan(50_000, 2, 1, 256, -1, cut_diag=True)
+    assert cost.max() <= 40 and pl["n_splits"] == 28           # (cost: without the per-item overhead of 6)
+    monkeypatch.setenv("GPT_VAR_CUT_DIAG", "0")
+    pl0, cost0 = _check_var_plan(50_000, 2, 1, 256, -1, cut_diag=False)
+    assert cost0.max() == 72 and pl0["n_splits"] == 14
+    monkeypatch.delenv("GPT_VAR_CUT_DIAG")
+    for cols, nbi in ((10_000, 16), (4096, 16), (500_000, 16), (10_000, 5), (4 * 500_000, 16)):
+        _check_var_plan(cols, nbi, 1, 256, -1, cut_diag=False)
+    for cols, nbi in ((4096, 2), (4096, 5), (50_000, 1), (460, 5), (64, 1), (16384 + 64, 16)):
+        _check_var_plan(cols, nbi, 1, 256, -1, cut_diag=True)
+    monkeypatch.setenv("GPT_VAR_CUT_DIAG", "1")                # forced: every shape must still be a partition the kernel can execute
+    rng = np.random.default_rng(11)
+    for _ in range(40):
+        P = int(rng.choice([1, 3, 8, 64, 256]))
+        _check_var_plan(int(rng.integers(1, 64 * 3 * P)), int(rng.integers(1, 20)), int(rng.choice([1, 1, 2, 3])), P, int(rng.integers(-1, 2)))
 
 
 def test_variance_work_plan_random_shapes():
