@@ -333,6 +333,12 @@ static __device__ __forceinline__ long long vt_clock() {
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");
     return t_;
 }
+// the chip-wide 100 MHz counter (s_memtime counts per XCD: workgroups on different XCDs cannot be compared with it)
+static __device__ __forceinline__ long long vt_realtime() {
+    long long t_;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");
+    return t_;
+}
 #define GPT_VT(i) do { if (vt_base && lane == 0 && it < VT_ITEMS) vt_base[(size_t)it * VT_STAMPS + (i)] = vt_clock(); } while (0)
 #else
 #define GPT_VT(i) do { } while (0)
@@ -376,9 +382,9 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
     long long* vt_base = nullptr;
     if (g_var_trace && (blockIdx.x == 0 || blockIdx.x == 37))
         vt_base = g_var_trace + ((size_t)(blockIdx.x == 0 ? 0 : 1) * 8 + w) * VT_ITEMS * VT_STAMPS;
-    // begin / end clock of every workgroup (wave 0), behind the phase stamps: [VT_WGS * 8 * VT_ITEMS * VT_STAMPS + 2 * blockIdx.x]
+    // begin / end time (100 MHz, chip-wide) of every workgroup (wave 0), behind the phase stamps: [VT_WGS * 8 * VT_ITEMS * VT_STAMPS + 2 * blockIdx.x]
     long long* const vt_wg = (g_var_trace && threadIdx.x == 0 && blockIdx.x < 1024) ? g_var_trace + (size_t)VT_WGS * 8 * VT_ITEMS * VT_STAMPS + 2 * blockIdx.x : nullptr;
-    if (vt_wg) vt_wg[0] = vt_clock();
+    if (vt_wg) vt_wg[0] = vt_realtime();
 #endif
 
     constexpr T RS2 = (T)0.70710678118654752440;    // coordinates are pre-scaled by 1/sqrt(2): t = ln c - |d'|^2
@@ -975,7 +981,7 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
         GPT_VT(8);
     }
 #ifdef GPT_VAR_TRACE
-    if (vt_wg) vt_wg[1] = vt_clock();
+    if (vt_wg) vt_wg[1] = vt_realtime();
 #endif
 }
 

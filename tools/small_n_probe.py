@@ -74,9 +74,11 @@ def main():
             if len(wg):          # (several launches per call: the last launch's stamps survive)
                 d = (wg[:, 1] - wg[:, 0]).astype(np.float64)
                 t0 = wg[:, 0].min()
-                print(f"  per-workgroup busy time of the last k_var launch, {len(wg)} workgroups (shader clocks): min {d.min():.0f}  median {np.median(d):.0f}  "
-                      f"max {d.max():.0f}  mean {d.mean():.0f};  launch span {int(wg[:, 1].max() - t0)};  latest start +{int(wg[:, 0].max() - t0)}")
-                print("    busy deciles: " + " ".join(f"{np.percentile(d, q):.0f}" for q in range(0, 101, 10)))
+                d *= 0.01; st = (wg[:, 0] - t0) * 0.01; en = (wg[:, 1] - t0) * 0.01       # 100 MHz chip-wide counter -> us
+                print(f"  per-workgroup busy time of the last k_var launch, {len(wg)} workgroups (us): min {d.min():.1f}  median {np.median(d):.1f}  "
+                      f"max {d.max():.1f}  mean {d.mean():.1f};  first start -> last end {en.max():.1f};  starts: median +{np.median(st):.1f} latest +{st.max():.1f};  "
+                      f"ends: earliest {en.min():.1f} median {np.median(en):.1f}")
+                print("    busy deciles (us): " + " ".join(f"{np.percentile(d, q):.1f}" for q in range(0, 101, 10)))
             for wi in range(VT_WGS):
                 t0 = tr[wi, 0, 0, 0]
                 print(f"  workgroup {'0' if wi == 0 else '37'}: (shader clocks; a full 512x512x64 tile = 128 k-steps x 2048 = 262144)")
