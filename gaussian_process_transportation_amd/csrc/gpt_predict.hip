@@ -52,6 +52,16 @@ template <> struct El<double> {
             acc[3][t] = mfma(a.hi[1], b[t], acc[3][t]);
         }
     }
+    // row tiles R0 .. 3 only (the last k-steps of a wave's diagonal 64 x 64 block: zeros above the diagonal)
+    template <int R0> static __device__ __forceinline__ void mfma_from(v4 (&acc)[4][4], const AF& a, const v4& b) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (R0 <= 0) acc[0][t] = mfma(a.lo[0], b[t], acc[0][t]);
+            if (R0 <= 1) acc[1][t] = mfma(a.lo[1], b[t], acc[1][t]);
+            if (R0 <= 2) acc[2][t] = mfma(a.hi[0], b[t], acc[2][t]);
+            acc[3][t] = mfma(a.hi[1], b[t], acc[3][t]);
+        }
+    }
 };
 template <> struct El<float> {
     typedef f4 v4;
@@ -84,6 +94,15 @@ template <> struct El<float> {
             acc[0][t] = mfma(a.v[0], b[t], acc[0][t]);
             acc[1][t] = mfma(a.v[1], b[t], acc[1][t]);
             acc[2][t] = mfma(a.v[2], b[t], acc[2][t]);
+            acc[3][t] = mfma(a.v[3], b[t], acc[3][t]);
+        }
+    }
+    template <int R0> static __device__ __forceinline__ void mfma_from(v4 (&acc)[4][4], const AF& a, const v4& b) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (R0 <= 0) acc[0][t] = mfma(a.v[0], b[t], acc[0][t]);
+            if (R0 <= 1) acc[1][t] = mfma(a.v[1], b[t], acc[1][t]);
+            if (R0 <= 2) acc[2][t] = mfma(a.v[2], b[t], acc[2][t]);
             acc[3][t] = mfma(a.v[3], b[t], acc[3][t]);
         }
     }
@@ -308,6 +327,9 @@ void launch_mean_jac(hipStream_t s, const KernelParams& p, const void* Xs, const
 // accumulators into the column sums.
 // -DGPT_VAR_TRACE (make trace): shader-clock stamps (s_memtime) of every wave of two workgroups at the phase boundaries of
 // their first VT_ITEMS items, written to the buffer set through gpt_debug_set_var_trace.
+#ifndef GPT_DIAG_TRIANGLE
+#define GPT_DIAG_TRIANGLE 1      // diagonal tiles: no MFMAs for the 16 x 16 blocks above the diagonal of a wave's own 64 x 64 block
+#endif
 #ifndef GPT_GEN_DIAG_FREE
 #define GPT_GEN_DIAG_FREE 1      // generating sweeps: diagonal tile barrier-free after its fragments went to the scratch image
 #endif
@@ -768,6 +790,30 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
                     const int kk = k < limit ? k : limit - 1;            // clamped: redundant, in bounds
                     El<T>::lda(a, ap + (size_t)kk * A_STEP, lane);
                 };
+                // The last 16 k-steps of a wave's range are its own 64 x 64 diagonal block of the factor (when the item's range reaches
+                // that far): W is lower triangular, so row tile r of the group has nothing but zeros from the block's k-step 4 (r + 1)
+                // on, and those MFMAs — 24 of the block's 64 tile-steps, 8 % of the whole tile — are not issued.  Adding 0 x b changes
+                // nothing, so results are the same to the bit.  body(first row tile with work, k4) runs RR steps from k4.
+                // (Not in the instantiations that sit at the register limit — cross terms, the fp64 3-column kernel, wide Matern: the
+                // peeled steps cost them a spilled pointer inside the ring loop, tools/check_isa_spills.py.)
+                constexpr bool TRI_OK = GPT_DIAG_TRIANGLE != 0 && !CROSS && !(std::is_same<T, double>::value && NCOMP == 3) && !(WIDE && KT != KT_RBF);
+                const bool tri = TRI_OK && limit == lim_g && limit > d_lo && GPT_ABL != 6;
+                auto tri_loop = [&](auto rtag, const int k_begin, const int k_end, const bool tri_end, auto&& body) {
+                    constexpr int RR = decltype(rtag)::value;
+                    static_assert(RR == 2 || RR == 4, "ring depth of the diagonal tile");
+                    const int k_main = tri_end ? k_end - 12 : k_end;
+                    for (int k4 = k_begin; k4 < k_main; k4 += RR) body(std::integral_constant<int, 0>{}, k4);
+                    if (tri_end) {
+                        if constexpr (RR == 4) {
+                            body(std::integral_constant<int, 1>{}, k_end - 12); body(std::integral_constant<int, 2>{}, k_end - 8);
+                            body(std::integral_constant<int, 3>{}, k_end - 4);
+                        } else {
+                            body(std::integral_constant<int, 1>{}, k_end - 12); body(std::integral_constant<int, 1>{}, k_end - 10);
+                            body(std::integral_constant<int, 2>{}, k_end - 8); body(std::integral_constant<int, 2>{}, k_end - 6);
+                            body(std::integral_constant<int, 3>{}, k_end - 4); body(std::integral_constant<int, 3>{}, k_end - 2);
+                        }
+                    }
+                };
                 if constexpr (El<T>::DIAG_LDS) {
                     // fp32: B through LDS.  With each wave re-reading its 16 (g + 1) steps of the B image from L2 / Infinity Cache
                     // (as the fp64 path below does) the tile cost 0.75 of a full one after all: 576 KiB per tile and workgroup
@@ -790,16 +836,16 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
                     }
                     __syncthreads();
                     v4 b_nxt = img[d_lo * 64 + lane];
-                    for (int k4 = d_lo; k4 < limit; k4 += DP) {
+                    tri_loop(std::integral_constant<int, DP>{}, d_lo, limit > d_lo ? limit : d_lo, tri, [&](auto jtag, const int k4) {
 #pragma unroll
                         for (int i = 0; i < DP; ++i) {
                             const v4 b = b_nxt;
                             const int kn = (k4 + i + 1 < limit) ? (k4 + i + 1) : (limit - 1);
                             b_nxt = img[kn * 64 + lane];
-                            El<T>::mfma16(acc, a[i], b);
+                            El<T>::template mfma_from<decltype(jtag)::value>(acc, a[i], b);
                             ldA(a[i], k4 + i + DP);
                         }
-                    }
+                    });
                     __syncthreads();                                     // the image is free again (next sweep's first fill)
                 } else {
                     // fp64: A from Wf and B straight from the scratch image, both one MFMA block (1024 cycles) ahead; program
@@ -853,47 +899,47 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
                         const int l1 = limit < 64 ? limit : 64;
                         const int p2 = d_lo > 64 ? d_lo : 64;             // first step that comes from the scratch image
                         v4 b_nxt = img[(d_lo < 64 ? d_lo : 63) * 64 + lane];
-                        for (int k4 = d_lo; k4 < l1; k4 += R) {
+                        tri_loop(std::integral_constant<int, R>{}, d_lo, l1 > d_lo ? l1 : d_lo, tri && limit <= 64, [&](auto jtag, const int k4) {
 #pragma unroll
                             for (int i = 0; i < R; ++i) {
                                 const v4 bb = b_nxt;
                                 const int kn = (k4 + i + 1 < l1) ? (k4 + i + 1) : (l1 - 1);
                                 b_nxt = img[kn * 64 + lane];
                                 __builtin_amdgcn_sched_barrier(0);
-                                El<T>::mfma16(acc, a[i], bb);
+                                El<T>::template mfma_from<decltype(jtag)::value>(acc, a[i], bb);
                                 __builtin_amdgcn_sched_barrier(0);
                                 ldA(a[i], k4 + i + R);
                             }
-                        }
+                        });
                         if (limit > p2) {
 #pragma unroll
                             for (int i = 0; i < R; ++i) ldB(b[i], p2 + i);
                         }
-                        for (int k4 = p2; k4 < limit; k4 += R) {
+                        tri_loop(std::integral_constant<int, R>{}, p2, limit > p2 ? limit : p2, tri && limit > 64, [&](auto jtag, const int k4) {
 #pragma unroll
                             for (int i = 0; i < R; ++i) {
                                 __builtin_amdgcn_sched_barrier(0);
-                                El<T>::mfma16(acc, a[i], b[i]);
+                                El<T>::template mfma_from<decltype(jtag)::value>(acc, a[i], b[i]);
                                 __builtin_amdgcn_sched_barrier(0);
                                 ldA(a[i], k4 + i + R); ldB(b[i], k4 + i + R);
                             }
-                        }
+                        });
                         __syncthreads();                                  // the image is free again (next sweep's first fill)
                     } else if constexpr (R == 2) {
                         AF a0, a1;
                         v4 b0, b1;
                         ldA(a0, d_lo); ldA(a1, d_lo + 1); ldB(b0, d_lo);
-                        for (int k4 = d_lo; k4 < limit; k4 += 2) {
+                        tri_loop(std::integral_constant<int, 2>{}, d_lo, limit > d_lo ? limit : d_lo, tri, [&](auto jtag, const int k4) {
                             ldB(b1, k4 + 1);
                             __builtin_amdgcn_sched_barrier(0);
-                            El<T>::mfma16(acc, a0, b0);
+                            El<T>::template mfma_from<decltype(jtag)::value>(acc, a0, b0);
                             __builtin_amdgcn_sched_barrier(0);
                             ldA(a0, k4 + 2); ldB(b0, k4 + 2);
                             __builtin_amdgcn_sched_barrier(0);
-                            El<T>::mfma16(acc, a1, b1);
+                            El<T>::template mfma_from<decltype(jtag)::value>(acc, a1, b1);
                             __builtin_amdgcn_sched_barrier(0);
                             ldA(a1, k4 + 3);
-                        }
+                        });
                     } else {
                         // Both operands R - 1 MFMA blocks ahead.  A wave alone on its SIMD (g = 7 for 112 of its 128 steps) has
                         // 1024 cycles per block, and the B image of a small model's block comes from beyond L2 (32 workgroups x
@@ -902,15 +948,15 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
                         v4 b[R];
 #pragma unroll
                         for (int i = 0; i < R; ++i) { ldA(a[i], d_lo + i); ldB(b[i], d_lo + i); }
-                        for (int k4 = d_lo; k4 < limit; k4 += R) {        // d_lo and limit are multiples of 16, R divides 16
+                        tri_loop(std::integral_constant<int, R>{}, d_lo, limit > d_lo ? limit : d_lo, tri, [&](auto jtag, const int k4) {     // d_lo and limit are multiples of 16, R divides 16
 #pragma unroll
                             for (int i = 0; i < R; ++i) {
                                 __builtin_amdgcn_sched_barrier(0);
-                                El<T>::mfma16(acc, a[i], b[i]);
+                                El<T>::template mfma_from<decltype(jtag)::value>(acc, a[i], b[i]);
                                 __builtin_amdgcn_sched_barrier(0);
                                 ldA(a[i], k4 + i + R); ldB(b[i], k4 + i + R);
                             }
-                        }
+                        });
                     }
                 }
             }
@@ -1093,7 +1139,7 @@ static void var_kernel_setup() {
     for (const void* f : fns) hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)var_lds_bytes<T>());
     if constexpr (std::is_same<T, double>::value) {       // the small-model instantiations (HALF): launch_var_t
         const void* hf[] = {reinterpret_cast<const void*>(k_var<T, 1, false, KT_RBF, 3, true, true>), reinterpret_cast<const void*>(k_var<T, 4, true, KT_RBF, 3, true, true>),
-                            reinterpret_cast<const void*>(k_var<T, 4, false, KT_RBF, 3, true, true>), reinterpret_cast<const void*>(k_var<T, 3, false, KT_RBF, 3, true, true>),
+                            reinterpret_cast<const void*>(k_var<T, 4, false, KT_RBF, 3, true, true>),
                             reinterpret_cast<const void*>(k_var<T, 1, false, KT_MATERN12, 3, true, true>), reinterpret_cast<const void*>(k_var<T, 1, false, KT_MATERN32, 3, true, true>),
                             reinterpret_cast<const void*>(k_var<T, 1, false, KT_MATERN52, 3, true, true>),
                             reinterpret_cast<const void*>(k_var<T, 1, false, KT_RBF, MAX_D, true, true>), reinterpret_cast<const void*>(k_var<T, 1, false, KT_MATERN12, MAX_D, true, true>),
@@ -1167,7 +1213,8 @@ static void launch_var_t(hipStream_t s, const KernelParams& p, const VarWorkspac
     } else if (ncomp == 1) {
         if (wide) { GPT_KVAR1(MAX_D) } else { GPT_KVAR1(3) }
     } else if (ncomp == 3) {      // Jacobian variance alone: D columns per query (D <= 3)
-        GPT_KVAR(3, false, KT_RBF, 3);
+        // (no HALF instantiation: at the register limit it keeps a spilled pointer inside the lock-step loop)
+        hipLaunchKernelGGL((k_var<T, 3, false, KT_RBF, 3>), grid, dim3(512), lds, s, p, pl, Xs, Wf, Xq, M, slab, vslab, bscr);
     } else if (ncomp == 4) {      // Jacobian variance / d var: RBF only (the API refuses other kernels)
         if (cross) GPT_KVAR(4, true, KT_RBF, 3);
         else GPT_KVAR(4, false, KT_RBF, 3);
