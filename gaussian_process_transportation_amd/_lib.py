@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("GPT_HIP_LIB") or os.path.join(_HERE, "libgpt_hip.so")
 
 GPT_OK, GPT_E_HIP, GPT_E_NOT_PD, GPT_E_ARG, GPT_E_STATE = 0, -1, -2, -3, -4
 GPT_F64, GPT_F32 = 0, 1
-MAX_D = 8          # input dimensions the library accepts (gpt_common.h: D <= 3 tuned layout, 4 .. 8 wide layout)
+MAX_D = 15         # input dimensions the library accepts (gpt_common.h MAX_DIMS: D <= 3 tuned layout, 4 .. 8 rows of 8, 9 .. 15 rows of 16)
 _NP_DTYPE = {GPT_F64: np.float64, GPT_F32: np.float32}
 
 _dp = C.POINTER(C.c_double)

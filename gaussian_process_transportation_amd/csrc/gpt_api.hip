@@ -36,7 +36,7 @@ constexpr int HDR_DOUBLES = 64;
 constexpr int HDR_TASK_C = 16;           // hdr[16 + t]: prior variance of task t (constant_value / outputscale)
 constexpr int MAX_TASKS = 32;
 constexpr int HDR_LS = 8;                // hdr[8 + d], d < 3: length-scale of dimension d
-constexpr int HDR_LS_HI = 48;            // hdr[48 + d - 3], 3 <= d < MAX_D: the further dimensions of the wide layout
+constexpr int HDR_LS_HI = 48;            // hdr[48 + d - 3], 3 <= d < MAX_DIMS: the further dimensions of the wide layouts (slots 48 .. 59)
 inline int hdr_ls_slot(int d) { return d < 3 ? HDR_LS + d : HDR_LS_HI + d - 3; }
 constexpr int64_t HOST_CHUNK = 1 << 17;  // queries per chunk of the host-pointer API (two chunks in flight)
 
@@ -155,7 +155,7 @@ struct gpt_handle {
     Layout lay{};
     bool have_layout = false, committed = false;
     KernelParams p{};
-    double jitter = 0, ls[MAX_D] = {1, 1, 1, 1, 1, 1, 1, 1};
+    double jitter = 0, ls[MAX_D] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
     int n_ls = 1;
     // fit workspace (fp64)
     double *dK = nullptr, *dW = nullptr, *dY4 = nullptr, *dT4 = nullptr, *dTa = nullptr, *dXs64 = nullptr, *dA64 = nullptr, *dscal = nullptr;
@@ -172,7 +172,7 @@ struct gpt_handle {
     // optimizer's objective) uploads nothing.  Cleared whenever the device copies are lost or overwritten.
     std::vector<double> hostX, hostY, hostY4;
     int hostX_D = 0, hostY_O = 0;
-    double host_scal[16] = {};     // landing area of the per-fit scalar read-back
+    double host_scal[2 + LML_TERMS + 4] = {};     // landing area of the per-fit scalar read-back
     double host_hdr[HDR_DOUBLES] = {};
     int host_info = 0;
     // staging of the host-pointer API, grow-only per buffer
@@ -260,7 +260,7 @@ int ensure_workspace(gpt_handle* h, int64_t NP, int npass) {
     HIPCHK(hipMalloc(&h->dTa, (size_t)NP * 4 * sizeof(double)));
     HIPCHK(hipMalloc(&h->dXs64, (size_t)NP * MAX_D * sizeof(double)));
     HIPCHK(hipMalloc(&h->dXraw, (size_t)NP * MAX_D * sizeof(double)));
-    HIPCHK(hipMalloc(&h->dscal, 16 * sizeof(double)));
+    HIPCHK(hipMalloc(&h->dscal, (2 + LML_TERMS + 4) * sizeof(double)));
     HIPCHK(hipMalloc(&h->dinfo, sizeof(int)));
     if (int rc = ensure_scratch(h, NP)) return rc;
     h->ws_np = NP; h->ws_npass = npass;
@@ -308,7 +308,7 @@ void fill_params(gpt_handle* h, const double* hdr) {
 
 int check_geometry(const char* who, int64_t N, int D, int O, const double* length_scale, int n_ls) {
     if (N < 1 || N > (1 << 20)) return fail(GPT_E_ARG, std::string(who) + ": N out of range");
-    if (D < 1 || D > MAX_D) return fail(GPT_E_ARG, std::string(who) + ": D must be 1 .. 8");
+    if (D < 1 || D > MAX_DIMS) return fail(GPT_E_ARG, std::string(who) + ": D must be 1 .. 15");
     if (O < 1) return fail(GPT_E_ARG, std::string(who) + ": O must be >= 1");
     if (n_ls != 1 && n_ls != D) return fail(GPT_E_ARG, std::string(who) + ": length_scale must have 1 or D entries");
     for (int d = 0; d < n_ls; ++d)
@@ -925,7 +925,7 @@ int gpt_factor_blob(gpt_handle* h, void** dev_ptr, size_t* bytes) {
 
 int gpt_factor_alloc_model(gpt_handle* h, int64_t N, int D, int O, int n_tasks, int dtype, void** dev_ptr, size_t* bytes) {
     if (!h || !dev_ptr || !bytes) return fail(GPT_E_ARG, "gpt_factor_alloc: NULL argument");
-    if (N < 1 || D < 1 || D > MAX_D || O < 1 || n_tasks < 1 || n_tasks > MAX_TASKS || (dtype != GPT_F64 && dtype != GPT_F32))
+    if (N < 1 || D < 1 || D > MAX_DIMS || O < 1 || n_tasks < 1 || n_tasks > MAX_TASKS || (dtype != GPT_F64 && dtype != GPT_F32))
         return fail(GPT_E_ARG, "gpt_factor_alloc: bad geometry");
     if (int rc = set_device(h)) return rc;
     h->committed = false;

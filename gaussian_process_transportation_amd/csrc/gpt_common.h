@@ -32,10 +32,15 @@ constexpr size_t WT_TILE_DOUBLES = (size_t)WT * WT;           // doubles per til
 // Cholesky panel width / diagonal block size.
 constexpr int NB = 64;
 // Input dimensions.  D <= 3 (the transport use: planar / spatial positions) is the tuned path: source rows of 4 elements
-// (x, y, z, 0), coordinates in registers.  3 < D <= MAX_D is the wide path: rows of 8, coordinate loops, query
-// coordinates staged through LDS in the variance kernel.
-constexpr int MAX_D = 8;
-inline int xs_stride(int D) { return D <= 3 ? 4 : 8; }
+// (x, y, z, 0), coordinates in registers.  3 < D <= MAX_DIMS is the wide path: rows of 8 (D <= 8) or 16 elements, coordinate
+// loops, query coordinates staged through LDS in the variance kernel.  MAX_DIMS = 15: a query's k* column and its D
+// derivative columns share one 16-column MFMA tile in the fused variance launch.
+constexpr int MAX_DIMS = 15;
+constexpr int MAX_D = 16;            // widest source row = size of every per-dimension array
+constexpr int WIDE_D = 8;            // the narrower of the two wide layouts
+inline int xs_stride(int D) { return D <= 3 ? 4 : (D <= WIDE_D ? WIDE_D : MAX_D); }
+// the DW template argument of the kernels that carry coordinates: 3 (rows of 4), 8 or 16
+inline int coord_width(int D) { return D <= 3 ? 3 : xs_stride(D); }
 // Columns per query of the fused variance launch (k*, dk_0 .. dk_{D-1}, zero columns up to a power of two).
 inline int var_fused_cols(int D) { return D <= 3 ? 4 : (D <= 7 ? 8 : 16); }
 // `ncomp` codes of var_prepare / launch_var: 1 = k* alone; 3 = Jacobian variance alone, D columns per query (D <= 3);
@@ -65,7 +70,7 @@ struct KernelParams {
     double lnc;          // log(constant_value)
     double noise;        // WhiteKernel noise_level
     double inv_ls[MAX_D];   // 1/length_scale per input dimension (unused dims: 0)
-    int D;               // input dims (1..MAX_D)
+    int D;               // input dims (1..MAX_DIMS)
     int O;               // outputs
     int N;               // source points
     int NP;              // padded source points
@@ -108,7 +113,7 @@ void launch_cov(hipStream_t s, const KernelParams& p, const double* Xs, const do
                 int Mp, double* KsT /* NP*Mp */, double* V /* NP*Mp */, double* VtV /* Mp*Mp */, double* cov_dev /* M*M */);
 // out: [d/dlog c, d/dlog l_0 .. l_{MAX_D-1}, d/dlog noise (per unit noise)] = LML_TERMS doubles
 constexpr int LML_TERMS = MAX_D + 2;
-constexpr int LML_PARTIAL_STRIDE = 16;
+constexpr int LML_PARTIAL_STRIDE = 20;      // >= LML_TERMS
 void launch_lml_terms(hipStream_t s, const double* Xs, int D, const double* A4, int npass, const double* Kinv, int N, int NP,
                       int O, int ktype, double c, double* partial /* (NP/64)^2*LML_PARTIAL_STRIDE doubles */, double* out /* LML_TERMS doubles */);
 // predict (buffers in the model's element type)

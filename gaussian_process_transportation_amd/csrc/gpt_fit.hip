@@ -23,7 +23,7 @@ struct InvLs { double v[MAX_D]; };       // 1 / length_scale per dimension, by v
 // block lower triangle; padded rows/cols get the identity so the factorisation stays PD.
 // HBM-write bound: one 64x64 tile per workgroup, 16 bytes per lane and store, 8 stores per thread.
 // =====================================================================================
-// DW = 3: rows of 4 (the tuned D <= 3 layout); DW = 8: rows of 8 (3 < D <= 8, unused coordinates are zero).
+// DW = 3: rows of 4 (the tuned D <= 3 layout); DW = 8 / 16: rows of 8 / 16 (3 < D <= 8 / <= 15, unused coordinates are zero).
 template <int DW>
 __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ Xs, int N, int NP, int ktype, double c,
                                               double diag_add, double* __restrict__ K) {
@@ -73,6 +73,7 @@ __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ Xs, int
 void launch_gram(hipStream_t s, const double* Xs, int D, int N, int NP, int ktype, double c, double diag_add, double* K) {
     dim3 grid(NP / 64, NP / 64);
     if (D <= 3) hipLaunchKernelGGL(k_gram<3>, grid, dim3(256), 0, s, Xs, N, NP, ktype, c, diag_add, K);
+    else if (D <= WIDE_D) hipLaunchKernelGGL(k_gram<WIDE_D>, grid, dim3(256), 0, s, Xs, N, NP, ktype, c, diag_add, K);
     else hipLaunchKernelGGL(k_gram<MAX_D>, grid, dim3(256), 0, s, Xs, N, NP, ktype, c, diag_add, K);
 }
 
@@ -1238,7 +1239,7 @@ void launch_kinv(hipStream_t s, const double* W, int NP, double* Kout) {
     launch_gemm<false, true>(s, g);
 }
 
-// Partial sums per workgroup: [0] d/dlog c, [1 + d] d/dlog l_d, [1 + DW] the noise term; DW = 3 / MAX_D as in k_gram.
+// Partial sums per workgroup: [0] d/dlog c, [1 + d] d/dlog l_d, [1 + DW] the noise term; DW = 3 / 8 / 16 as in k_gram.
 template <int DW>
 __global__ __launch_bounds__(256) void k_lml_terms(const double* __restrict__ Xs, const double* __restrict__ A4, int npass,
                                                    const double* __restrict__ Kinv, int N, int NP, int O, int ktype, double c,
@@ -1341,6 +1342,9 @@ void launch_lml_terms(hipStream_t s, const double* Xs, int D, const double* A4, 
     if (D <= 3) {
         hipLaunchKernelGGL(k_lml_terms<3>, dim3(nb, nb), dim3(256), 0, s, Xs, A4, npass, Kinv, N, NP, O, ktype, c, partial);
         hipLaunchKernelGGL(k_sum_partials<3>, dim3(1), dim3(256), 0, s, partial, nb * nb, out);
+    } else if (D <= WIDE_D) {
+        hipLaunchKernelGGL(k_lml_terms<WIDE_D>, dim3(nb, nb), dim3(256), 0, s, Xs, A4, npass, Kinv, N, NP, O, ktype, c, partial);
+        hipLaunchKernelGGL(k_sum_partials<WIDE_D>, dim3(1), dim3(256), 0, s, partial, nb * nb, out);
     } else {
         hipLaunchKernelGGL(k_lml_terms<MAX_D>, dim3(nb, nb), dim3(256), 0, s, Xs, A4, npass, Kinv, N, NP, O, ktype, c, partial);
         hipLaunchKernelGGL(k_sum_partials<MAX_D>, dim3(1), dim3(256), 0, s, partial, nb * nb, out);

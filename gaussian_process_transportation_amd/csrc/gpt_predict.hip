@@ -110,7 +110,7 @@ template <> struct El<float> {
 
 // ------------------------------------------------------------------------------------------
 // OC = outputs handled by this pass (1..4): only their partial sums are accumulated.
-// DW = coordinates carried per point: 3 (source rows of 4: the tuned D <= 3 layout) or MAX_D (rows of 8, D = 4..8).
+// DW = coordinates carried per point: 3 (source rows of 4: the tuned D <= 3 layout), WIDE_D (rows of 8, D = 4..8) or MAX_D (rows of 16, D = 9..15).
 // WJ = false: the mean alone (predict without derivative: configs[1]) — no Jacobian sums, a third fewer vector instructions.
 template <typename T, int QPW, int OC, int KT, int DW, bool WJ = true>
 __global__ __launch_bounds__(256) void k_mean_jac(KernelParams p, const T* __restrict__ Xs,
@@ -265,6 +265,11 @@ void launch_mean_jac(hipStream_t s, const KernelParams& p, const void* Xs, const
             launch_mean_jac_t<float, 3>(s, p, (const float*)Xs, (const float*)A4, (const float*)Xq, M, (float*)mean, (float*)J);
         else
             launch_mean_jac_t<double, 3>(s, p, (const double*)Xs, (const double*)A4, (const double*)Xq, M, (double*)mean, (double*)J);
+    } else if (p.D <= WIDE_D) {
+        if (p.dtype == DT_F32)
+            launch_mean_jac_t<float, WIDE_D>(s, p, (const float*)Xs, (const float*)A4, (const float*)Xq, M, (float*)mean, (float*)J);
+        else
+            launch_mean_jac_t<double, WIDE_D>(s, p, (const double*)Xs, (const double*)A4, (const double*)Xq, M, (double*)mean, (double*)J);
     } else {
         if (p.dtype == DT_F32)
             launch_mean_jac_t<float, MAX_D>(s, p, (const float*)Xs, (const float*)A4, (const float*)Xq, M, (float*)mean, (float*)J);
@@ -308,7 +313,7 @@ void launch_mean_jac(hipStream_t s, const KernelParams& p, const void* Xs, const
 // hit rate 97 % -> 56 %, 3.4 TB/s from beyond L2, clock 2.18 GHz), deeper A prefetch (0 %).
 // NCOMP = 1: one column per query (k*).  NCOMP = 4: four columns per query (k*, dk_0, dk_1, dk_2).
 // NCOMP = 3: D columns per query (dk_0 .. dk_{D-1}) — the Jacobian variance without the variance.
-// DW = 3 is all of the above: D <= 3, source rows of 4 elements, query coordinates in registers.  DW = MAX_D is the
+// DW = 3 is all of the above: D <= 3, source rows of 4 elements, query coordinates in registers.  DW = WIDE_D is the
 // wide path for D = 4 .. 8 (rows of 8): only the generating sweep differs — the block's query coordinates sit in LDS
 // (qs[d][query]), distances are coordinate loops — with NCOMP = 1, or NCOMP = 8 / 16: k*, dk_0 .. dk_{D-1} and zero
 // columns up to 8 (D <= 7) or 16 per query, so that a query's columns stay inside one 16-column MFMA tile.  KSTAR = false
@@ -387,7 +392,8 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
     constexpr bool WIDE = DW != 3;
     constexpr int XS = WIDE ? DW : 4;                   // elements per source row
     constexpr int CPQ = NCOMP >= 4 ? NCOMP : 1;         // columns per query when they sit side by side (a power of two)
-    static_assert(!WIDE || (DW == 8 && (NCOMP == 1 || NCOMP == 8 || NCOMP == 16 || (!KSTAR && NCOMP == 4))), "wide path: rows of 8, NCOMP 1 / 8 / 16 (4 / 8 without k*)");
+    static_assert(!WIDE || (DW == 8 && (NCOMP == 1 || NCOMP == 8 || NCOMP == 16 || (!KSTAR && NCOMP == 4))) || (DW == 16 && KSTAR && (NCOMP == 1 || NCOMP == 16)),
+                  "wide path: rows of 8, NCOMP 1 / 8 / 16 (4 / 8 without k*); rows of 16, NCOMP 1 / 16");
     static_assert(WIDE || NCOMP == 1 || NCOMP == 3 || NCOMP == 4, "D <= 3: NCOMP 1 / 3 / 4");
     static_assert(KSTAR || (WIDE && !CROSS && (NCOMP == 4 || NCOMP == 8)), "no k* column: wide path, Jacobian variance alone");
     __shared__ T red[2][8][VAR_COLS];
@@ -474,14 +480,18 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
             __syncthreads();                               // nobody may still be reading the part of the image rewritten now
         }
         if (WIDE && (flags & VI_FIRST)) {
-            // the block's queries (64 for NCOMP = 1, 64 / NCOMP otherwise), coordinate w by wave w, scaled as the sources are
+            // the block's queries (64 for NCOMP = 1, 64 / NCOMP otherwise), coordinate w (and w + 8 in rows of 16) by wave w, scaled as the sources are
             constexpr int NQ = VAR_COLS / (CPQ > 1 ? CPQ : 1);
-            double il = 0.0;
-#pragma unroll
-            for (int d = 0; d < DW; ++d) if (d == w) il = p.inv_ls[d];
             const int64_t m = cb * NQ + lane;
             const int64_t mm = (m < M) ? m : (M - 1);
-            if (lane < NQ) qs[w][lane] = (w < D) ? Xq[mm * D + w] * (T)(il * 0.70710678118654752440) : (T)0;
+#pragma unroll
+            for (int c0 = 0; c0 < DW; c0 += 8) {
+                const int cw = c0 + w;
+                double il = 0.0;
+#pragma unroll
+                for (int d = 0; d < DW; ++d) if (d == cw) il = p.inv_ls[d];
+                if (lane < NQ) qs[cw][lane] = (cw < D) ? Xq[mm * D + cw] * (T)(il * 0.70710678118654752440) : (T)0;
+            }
             __syncthreads();
         }
         if (flags & VI_ZERO) {
@@ -1131,21 +1141,24 @@ static void var_kernel_setup() {
                          reinterpret_cast<const void*>(k_var<T, 1, false, KT_MATERN12>),
                          reinterpret_cast<const void*>(k_var<T, 1, false, KT_MATERN32>), reinterpret_cast<const void*>(k_var<T, 1, false, KT_MATERN52>),
                          // D = 4 .. 8
+                         reinterpret_cast<const void*>(k_var<T, 1, false, KT_RBF, WIDE_D>), reinterpret_cast<const void*>(k_var<T, 1, false, KT_MATERN12, WIDE_D>),
+                         reinterpret_cast<const void*>(k_var<T, 1, false, KT_MATERN32, WIDE_D>), reinterpret_cast<const void*>(k_var<T, 1, false, KT_MATERN52, WIDE_D>),
+                         reinterpret_cast<const void*>(k_var<T, 8, true, KT_RBF, WIDE_D>), reinterpret_cast<const void*>(k_var<T, 8, false, KT_RBF, WIDE_D>),
+                         reinterpret_cast<const void*>(k_var<T, 16, true, KT_RBF, WIDE_D>), reinterpret_cast<const void*>(k_var<T, 16, false, KT_RBF, WIDE_D>),
+                         reinterpret_cast<const void*>(k_var<T, 4, false, KT_RBF, WIDE_D, false>), reinterpret_cast<const void*>(k_var<T, 8, false, KT_RBF, WIDE_D, false>),
                          reinterpret_cast<const void*>(k_var<T, 1, false, KT_RBF, MAX_D>), reinterpret_cast<const void*>(k_var<T, 1, false, KT_MATERN12, MAX_D>),
                          reinterpret_cast<const void*>(k_var<T, 1, false, KT_MATERN32, MAX_D>), reinterpret_cast<const void*>(k_var<T, 1, false, KT_MATERN52, MAX_D>),
-                         reinterpret_cast<const void*>(k_var<T, 8, true, KT_RBF, MAX_D>), reinterpret_cast<const void*>(k_var<T, 8, false, KT_RBF, MAX_D>),
-                         reinterpret_cast<const void*>(k_var<T, 16, true, KT_RBF, MAX_D>), reinterpret_cast<const void*>(k_var<T, 16, false, KT_RBF, MAX_D>),
-                         reinterpret_cast<const void*>(k_var<T, 4, false, KT_RBF, MAX_D, false>), reinterpret_cast<const void*>(k_var<T, 8, false, KT_RBF, MAX_D, false>)};
+                         reinterpret_cast<const void*>(k_var<T, 16, true, KT_RBF, MAX_D>), reinterpret_cast<const void*>(k_var<T, 16, false, KT_RBF, MAX_D>)};
     for (const void* f : fns) hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)var_lds_bytes<T>());
     if constexpr (std::is_same<T, double>::value) {       // the small-model instantiations (HALF): launch_var_t
         const void* hf[] = {reinterpret_cast<const void*>(k_var<T, 1, false, KT_RBF, 3, true, true>), reinterpret_cast<const void*>(k_var<T, 4, true, KT_RBF, 3, true, true>),
                             reinterpret_cast<const void*>(k_var<T, 4, false, KT_RBF, 3, true, true>),
                             reinterpret_cast<const void*>(k_var<T, 1, false, KT_MATERN12, 3, true, true>), reinterpret_cast<const void*>(k_var<T, 1, false, KT_MATERN32, 3, true, true>),
                             reinterpret_cast<const void*>(k_var<T, 1, false, KT_MATERN52, 3, true, true>),
-                            reinterpret_cast<const void*>(k_var<T, 1, false, KT_RBF, MAX_D, true, true>), reinterpret_cast<const void*>(k_var<T, 1, false, KT_MATERN12, MAX_D, true, true>),
-                            reinterpret_cast<const void*>(k_var<T, 1, false, KT_MATERN32, MAX_D, true, true>), reinterpret_cast<const void*>(k_var<T, 1, false, KT_MATERN52, MAX_D, true, true>),
-                            reinterpret_cast<const void*>(k_var<T, 8, true, KT_RBF, MAX_D, true, true>), reinterpret_cast<const void*>(k_var<T, 8, false, KT_RBF, MAX_D, true, true>),
-                            reinterpret_cast<const void*>(k_var<T, 16, true, KT_RBF, MAX_D, true, true>), reinterpret_cast<const void*>(k_var<T, 16, false, KT_RBF, MAX_D, true, true>)};
+                            reinterpret_cast<const void*>(k_var<T, 1, false, KT_RBF, WIDE_D, true, true>), reinterpret_cast<const void*>(k_var<T, 1, false, KT_MATERN12, WIDE_D, true, true>),
+                            reinterpret_cast<const void*>(k_var<T, 1, false, KT_MATERN32, WIDE_D, true, true>), reinterpret_cast<const void*>(k_var<T, 1, false, KT_MATERN52, WIDE_D, true, true>),
+                            reinterpret_cast<const void*>(k_var<T, 8, true, KT_RBF, WIDE_D, true, true>), reinterpret_cast<const void*>(k_var<T, 8, false, KT_RBF, WIDE_D, true, true>),
+                            reinterpret_cast<const void*>(k_var<T, 16, true, KT_RBF, WIDE_D, true, true>), reinterpret_cast<const void*>(k_var<T, 16, false, KT_RBF, WIDE_D, true, true>)};
         for (const void* f : hf) hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)var_lds_bytes<T>());
     }
     });
@@ -1168,7 +1181,7 @@ static void launch_var_t(hipStream_t s, const KernelParams& p, const VarWorkspac
     T* vslab = static_cast<T*>(ws.vslab);
     T* bscr = static_cast<T*>(ws.bscratch);
     const dim3 grid((unsigned)pl_all.P), fgrid((unsigned)pl_all.ncb), cgrid((unsigned)pl_all.n_splits * VAR_SPLIT_SLOTS);
-    const bool wide = p.D > 3;
+    const bool wide = p.D > 3, wide16 = p.D > WIDE_D;
     const bool cross = ncomp >= 4 && dvar != nullptr;
     // The persistent workgroups are not synchronised between rounds and drift apart; once they are further apart than a W
     // tile stays in L2 each fetches its own copy of the W stream (mode J+Jvar, 122 rounds in one launch: 155 MB fetched per
@@ -1207,11 +1220,19 @@ static void launch_var_t(hipStream_t s, const KernelParams& p, const VarWorkspac
             default: GPT_KVAR(1, false, KT_RBF, DW_); break;             \
         }
     if (ncomp == VAR_NCOMP_DERIV4) {          // D = 4, Jacobian variance alone: dk_0 .. dk_3
-        hipLaunchKernelGGL((k_var<T, 4, false, KT_RBF, MAX_D, false>), grid, dim3(512), lds, s, p, pl, Xs, Wf, Xq, M, slab, vslab, bscr);
+        hipLaunchKernelGGL((k_var<T, 4, false, KT_RBF, WIDE_D, false>), grid, dim3(512), lds, s, p, pl, Xs, Wf, Xq, M, slab, vslab, bscr);
     } else if (ncomp == VAR_NCOMP_DERIV8) {   // D = 8
-        hipLaunchKernelGGL((k_var<T, 8, false, KT_RBF, MAX_D, false>), grid, dim3(512), lds, s, p, pl, Xs, Wf, Xq, M, slab, vslab, bscr);
+        hipLaunchKernelGGL((k_var<T, 8, false, KT_RBF, WIDE_D, false>), grid, dim3(512), lds, s, p, pl, Xs, Wf, Xq, M, slab, vslab, bscr);
     } else if (ncomp == 1) {
-        if (wide) { GPT_KVAR1(MAX_D) } else { GPT_KVAR1(3) }
+        if (wide16) {             // D = 9 .. 15: rows of 16 (no HALF instantiations)
+#define GPT_KVAR16(NC_, CR_, KT_) hipLaunchKernelGGL((k_var<T, NC_, CR_, KT_, MAX_D>), grid, dim3(512), lds, s, p, pl, Xs, Wf, Xq, M, slab, vslab, bscr)
+            switch (p.ktype) {
+                case KT_MATERN12: GPT_KVAR16(1, false, KT_MATERN12); break;
+                case KT_MATERN32: GPT_KVAR16(1, false, KT_MATERN32); break;
+                case KT_MATERN52: GPT_KVAR16(1, false, KT_MATERN52); break;
+                default: GPT_KVAR16(1, false, KT_RBF); break;
+            }
+        } else if (wide) { GPT_KVAR1(WIDE_D) } else { GPT_KVAR1(3) }
     } else if (ncomp == 3) {      // Jacobian variance alone: D columns per query (D <= 3)
         // (no HALF instantiation: at the register limit it keeps a spilled pointer inside the lock-step loop)
         hipLaunchKernelGGL((k_var<T, 3, false, KT_RBF, 3>), grid, dim3(512), lds, s, p, pl, Xs, Wf, Xq, M, slab, vslab, bscr);
@@ -1219,13 +1240,17 @@ static void launch_var_t(hipStream_t s, const KernelParams& p, const VarWorkspac
         if (cross) GPT_KVAR(4, true, KT_RBF, 3);
         else GPT_KVAR(4, false, KT_RBF, 3);
     } else if (ncomp == 8) {      // D = 4 .. 7
-        if (cross) GPT_KVAR(8, true, KT_RBF, MAX_D);
-        else GPT_KVAR(8, false, KT_RBF, MAX_D);
+        if (cross) GPT_KVAR(8, true, KT_RBF, WIDE_D);
+        else GPT_KVAR(8, false, KT_RBF, WIDE_D);
+    } else if (wide16) {          // D = 9 .. 15
+        if (cross) GPT_KVAR16(16, true, KT_RBF);
+        else GPT_KVAR16(16, false, KT_RBF);
     } else {                      // D = 8
-        if (cross) GPT_KVAR(16, true, KT_RBF, MAX_D);
-        else GPT_KVAR(16, false, KT_RBF, MAX_D);
+        if (cross) GPT_KVAR(16, true, KT_RBF, WIDE_D);
+        else GPT_KVAR(16, false, KT_RBF, WIDE_D);
     }
     }
+#undef GPT_KVAR16
 #undef GPT_KVAR1
 #undef GPT_KVAR
     const VarPlanDev& pl = pl_all;

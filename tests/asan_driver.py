@@ -23,12 +23,12 @@ for bad in (lambda: _lib.Handle(3), lambda: h.predict_all(np.zeros((2, 3)), mean
         continue
     raise AssertionError("an invalid call went through")
 
-for bad in (lambda: h.fit(np.zeros((3, 9)), np.zeros((3, 2)), [1.0], 1.0, 0.1, 0.0),):        # D beyond MAX_D
+for bad in (lambda: h.fit(np.zeros((3, 16)), np.zeros((3, 2)), [1.0], 1.0, 0.1, 0.0),):        # D beyond MAX_DIMS
     try:
         bad()
     except ValueError:
         continue
-    raise AssertionError("D = 9 went through")
+    raise AssertionError("D = 16 went through")
 
 for N, D, O in ((1, 1, 1), (700, 3, 3), (1100, 2, 6), (530, 5, 5), (200, 8, 2), (64, 4, 1)):
     X = rng.uniform(0, 1, (N, D)); Y = rng.standard_normal((N, O))

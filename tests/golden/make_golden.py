@@ -321,7 +321,7 @@ def case_n8192(pt):
 def main(argv):
     warnings.filterwarnings("ignore")
     pt, resample = import_reference()
-    cases = argv or ["n64", "n64iso", "n64nan", "n256", "n1024", "n200d5", "n128d8", "letterS", "matern", "matern5d", "robot"]
+    cases = argv or ["n64", "n64iso", "n64nan", "n256", "n1024", "n200d5", "n128d8", "n160d12", "n96d15", "letterS", "matern", "matern5d", "robot"]
     for c in cases:
         if c == "n64":
             case_synthetic(pt, 64, 48, "synthetic_3d_N64", with_cov=16)
@@ -337,6 +337,10 @@ def main(argv):
             case_synthetic(pt, 200, 80, "synthetic_5d_N200", ls=(0.3, 0.5, 0.4, 0.6, 0.35), with_cov=12, D=5)
         elif c == "n128d8":
             case_synthetic(pt, 128, 40, "synthetic_8d_N128", ls=(0.7,), with_cov=8, D=8)
+        elif c == "n160d12":    # input dimension beyond 8: source rows of 16 (ARD length-scales, 12 outputs = three passes of 4)
+            case_synthetic(pt, 160, 60, "synthetic_12d_N160", ls=tuple(0.8 + 0.05 * d for d in range(12)), with_cov=8, D=12)
+        elif c == "n96d15":     # the largest dimension the HIP path takes: k* and 15 derivative columns fill one 16-column tile
+            case_synthetic(pt, 96, 40, "synthetic_15d_N96", ls=(1.1,), with_cov=8, D=15)
         elif c == "letterS":
             case_letterS(pt, resample)
         elif c == "matern":

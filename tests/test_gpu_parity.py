@@ -39,7 +39,7 @@ def fitted_gp(g):
 
 
 SYN = ["synthetic_3d_N64", "synthetic_3d_N64_iso", "synthetic_3d_N64_nan", "synthetic_3d_N256", "synthetic_3d_N1024",
-       "synthetic_5d_N200", "synthetic_8d_N128"]          # the last two: input dimension beyond 3 (the wide layout)
+       "synthetic_5d_N200", "synthetic_8d_N128", "synthetic_12d_N160", "synthetic_15d_N96"]          # the last four: input dimension beyond 3 (the wide layouts: rows of 8 and of 16)
 
 
 @pytest.mark.parametrize("name", SYN)
@@ -484,7 +484,7 @@ def test_full_size_properties():
 
 
 @pytest.mark.parametrize("name", ["synthetic_3d_N64", "synthetic_3d_N64_iso", "synthetic_3d_N256", "synthetic_3d_N1024",
-                                  "synthetic_5d_N200", "synthetic_8d_N128"])
+                                  "synthetic_5d_N200", "synthetic_8d_N128", "synthetic_12d_N160", "synthetic_15d_N96"])
 def test_lml_value_and_gradient_vs_sklearn(name):
     """gpt_lml_gradient against sklearn's log_marginal_likelihood(theta, eval_gradient=True) at three thetas."""
     from gaussian_process_transportation_amd import _lib
@@ -1023,7 +1023,7 @@ def test_non_finite_inputs_raise_like_sklearn():
             call()
     h = _lib.Handle(0)
     with pytest.raises(ValueError):
-        h.fit(np.zeros((4, 9)), np.zeros((4, 1)), [1.0], 1.0, 1e-3, 0.0)       # D = 9: beyond the documented limit of 8
+        h.fit(np.zeros((4, 16)), np.zeros((4, 1)), [1.0], 1.0, 1e-3, 0.0)       # D = 16: beyond the documented limit of 15
 
 
 def test_covariance_needs_the_inverse_factor_of_the_committed_model():
@@ -1416,6 +1416,67 @@ def test_matern_kernels_in_five_dimensions_vs_reference(tag, nu, code):
         with pytest.raises(ValueError):
             h.predict_all(big[:5], J=True)                     # RBF-only formulas (reference quirk 6): refused
         h.close()
+
+
+@pytest.mark.parametrize("D", [9, 12, 15])
+def test_rows_of_sixteen_layout_against_the_oracle(D):
+    """Input dimension 9 .. 15: source rows of 16 (k_gram<16>, k_mean_jac<.., 16>, k_var<.., DW = 16> with NCOMP 1 and 16,
+    k_lml_terms<16>).  The reference fixtures synthetic_12d_N160 / synthetic_15d_N96 pin the small case (test_golden_*); this is a
+    model of several i-blocks with a tail in the variance launch: every output against the CPU oracle, the fp32 model against the
+    fp64 one, a Matern kernel (mean + variance), the posterior covariance of a few queries and LML + gradient against the
+    oracle's (itself pinned to sklearn's by the fixtures)."""
+    from gaussian_process_transportation_amd import _lib
+    from oracle import gp_oracle as orc
+    rng = np.random.default_rng(100 + D)
+    N, M = 1300, 2500
+    X = rng.uniform(0, 1, (N, D)); Y = np.column_stack([np.sin(X.sum(1)), np.cos(2 * X[:, 0] - X[:, D - 1])]); Xq = rng.uniform(-0.05, 1.05, (M, D))
+    c, ls, noise, jit = 0.6, np.linspace(0.9, 1.6, D), 1e-3, 1e-10
+    h = _lib.Handle(0)
+    h.fit(X, Y, ls, c, noise, jit)
+    out = h.predict_all(Xq, mean=True, var=True, J=True, Jvar=True, dvar=True)
+    only_var = h.predict_all(Xq, var=True)
+    only_jv = h.predict_all(Xq, Jvar=True)
+    L, a = orc.gpr_fit(X, Y, c, ls, noise, jit)
+    idx = np.arange(0, M, 5)
+    mean, var, J, Jvar = orc.posterior_all_fast(Xq[idx], X, L, a, c, ls, noise, want_jvar=True)
+    assert_parity(out["mean"][idx], mean, RTOL, "mean")
+    assert_parity(out["var"][idx], var, RTOL, "var")
+    assert_parity(out["J"][idx], J, RTOL, "J")
+    assert_parity(out["Jvar"][idx], Jvar, RTOL, "Jvar")
+    assert_parity(only_var["var"], out["var"], 1e-10, "var alone vs fused launch")
+    assert_parity(only_jv["Jvar"], out["Jvar"], 1e-10, "Jvar alone vs fused launch")
+    eps = 1e-5
+    sub = idx[:40]
+    for d in (0, D // 2, D - 1):                                # d var / d x against central differences of var
+        e = np.zeros(D); e[d] = eps
+        vp = h.predict_all(Xq[sub] + e, var=True)["var"]; vm = h.predict_all(Xq[sub] - e, var=True)["var"]
+        assert_parity(out["dvar"][d][sub], (vp - vm) / (2 * eps), 1e-4, f"dvar[{d}] vs finite difference")
+    _, cov = h.predict_cov(Xq[:10])
+    assert_parity(np.diag(cov), out["var"][:10], 1e-8, "diag of the posterior covariance")
+    _, cov_o = orc.gpr_predict(Xq[:10], X, L, a, c, ls, noise, return_cov=True)
+    assert_parity(cov, cov_o[..., 0], 1e-7, "posterior covariance")
+    lml, grad = h.lml_gradient(D)
+    lml_o, grad_o = orc.log_marginal_likelihood(np.log(np.concatenate([[c], ls, [noise]])), X, Y, D, jit)
+    assert lml == pytest.approx(float(lml_o), rel=1e-9)
+    assert_parity(grad, grad_o, 1e-6, "d lml / d theta")
+    # fp32 model
+    h.set_dtype(_lib.GPT_F32)
+    h.fit(X, Y, ls, c, noise, jit)
+    o32 = h.predict_all(Xq, mean=True, var=True, J=True, Jvar=True)
+    assert o32["mean"].dtype == np.float32
+    assert_parity(o32["mean"], out["mean"], 5e-4, "mean (fp32 model)")
+    assert_parity(o32["J"], out["J"], 5e-4, "J (fp32 model)")
+    assert np.max(np.abs(o32["var"] - out["var"])) < 5e-4 * (c + noise)
+    assert np.max(np.abs(o32["Jvar"] - out["Jvar"])) < 5e-4 * np.max(out["Jvar"])
+    # Matern 3/2: mean + variance
+    h.set_dtype(_lib.GPT_F64)
+    h.fit(X, Y, ls, c, noise, jit, 2)
+    om = h.predict_all(Xq[idx], mean=True, var=True)
+    Lm, am = orc.gpr_fit(X, Y, c, ls, noise, jit, kind="matern32")
+    mm, sm = orc.gpr_predict(Xq[idx], X, Lm, am, c, ls, noise, return_std=True, kind="matern32")
+    assert_parity(om["mean"], mm, RTOL, "mean (Matern 3/2)")
+    assert_parity(om["var"], sm[:, 0] ** 2, RTOL, "var (Matern 3/2)")
+    h.close()
 
 
 def test_transport_orientation_on_the_recorded_robot_demo():

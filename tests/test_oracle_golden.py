@@ -8,7 +8,7 @@ from tests.conftest import assert_parity, load_golden
 
 TIGHT = 1e-9      # oracle vs reference: both fp64 CPU, same algorithm
 SYN = ["synthetic_3d_N64", "synthetic_3d_N64_iso", "synthetic_3d_N64_nan", "synthetic_3d_N256",
-       "synthetic_3d_N1024", "synthetic_5d_N200", "synthetic_8d_N128"]
+       "synthetic_3d_N1024", "synthetic_5d_N200", "synthetic_8d_N128", "synthetic_12d_N160", "synthetic_15d_N96"]
 
 
 def fitted(g):
@@ -54,7 +54,7 @@ def test_predict_and_derivatives(name):
         assert_parity(gp.samples(Xq[:n]), g["samples"], 1e-6, "samples")
 
 
-@pytest.mark.parametrize("name", ["synthetic_3d_N64", "synthetic_3d_N256", "synthetic_5d_N200", "synthetic_8d_N128"])
+@pytest.mark.parametrize("name", ["synthetic_3d_N64", "synthetic_3d_N256", "synthetic_5d_N200", "synthetic_8d_N128", "synthetic_12d_N160", "synthetic_15d_N96"])
 def test_fast_variant_matches_faithful(name):
     g = load_golden(name)
     gp = fitted(g)
@@ -66,7 +66,7 @@ def test_fast_variant_matches_faithful(name):
     assert_parity(Jvar, g["Jvar"][:, 0, :], 1e-7, "Jvar")
 
 
-@pytest.mark.parametrize("name", ["synthetic_3d_N64", "synthetic_3d_N64_iso", "synthetic_3d_N256", "synthetic_5d_N200", "synthetic_8d_N128"])
+@pytest.mark.parametrize("name", ["synthetic_3d_N64", "synthetic_3d_N64_iso", "synthetic_3d_N256", "synthetic_5d_N200", "synthetic_8d_N128", "synthetic_12d_N160", "synthetic_15d_N96"])
 def test_lml_and_gradient(name):
     g = load_golden(name)
     n_ls = g["length_scale"].size

@@ -31,7 +31,7 @@ for name in re.findall(r"^(_ZN3gpt5k_varI\w+):", s, flags=re.M):
     blocks.append(cur)
     hot = [b for b in blocks if sum("v_mfma" in x for x in b) >= 64 and not any("v_exp" in x or "v_ldexp" in x for x in b)]
     spilled = [sum("scratch_" in x for x in b) for b in hot]
-    tag = re.search(r"k_varI(\w)Li(\d+)ELb(\d)ELi(\d)ELi(\d)ELb(\d)ELb(\d)", name).groups()
+    tag = re.search(r"k_varI(\w)Li(\d+)ELb(\d)ELi(\d)ELi(\d+)ELb(\d)ELb(\d)", name).groups()
     total_scratch = sum("scratch_" in x for x in body.split("\n"))
     print(f"k_var<{'double' if tag[0] == 'd' else 'float'}, NCOMP={tag[1]}, CROSS={tag[2]}, KT={tag[3]}, DW={tag[4]}, KSTAR={tag[5]}, HALF={tag[6]}>: vgprs {vg.group(1) if vg else '?'}, "
           f"scratch ops anywhere {total_scratch}, "

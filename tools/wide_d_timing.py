@@ -1,4 +1,4 @@
-"""Throughput of the wide layout (input dimension 4 .. 8) next to the tuned D = 3 path, device-resident inputs,
+"""Throughput of the wide layouts (input dimension 4 .. 8: rows of 8; 9 .. 15: rows of 16) next to the tuned D = 3 path, device-resident inputs,
 N = 8192 sources: mean + variance + Jacobian ("J": one k* column per query) and the same with the Jacobian variance
 ("JVAR": 4 / 8 / 16 columns per query, of which 1 + D carry data).  k_var's rate is quoted on the columns it multiplies
 (including the zero columns of the wide fused layout) and on the useful ones.
@@ -18,7 +18,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 M = int(sys.argv[2]) if len(sys.argv) > 2 else 200_000
 for dtype, tname, peak in ((_lib.GPT_F64, "fp64", 78.6e12), (_lib.GPT_F32, "fp32", 157.3e12)):
     tt = torch.float64 if dtype == _lib.GPT_F64 else torch.float32
-    for D in (3, 4, 6, 7, 8):
+    for D in (3, 4, 6, 8, 9, 12, 15):
         rng = np.random.default_rng(0)
         X = rng.uniform(0, 1, (N, D)); Y = np.sin(4 * X[:, :3])
         h = _lib.Handle(0)
