@@ -351,7 +351,7 @@ void launch_mean_jac(hipStream_t s, const KernelParams& p, const void* Xs, const
 #define GPT_DIAG_RING 4          // fp64 barrier-free diagonal tile: operand ring depth (2 = the loop of rounds 1-3)
 #endif
 #ifdef GPT_VAR_TRACE
-constexpr int VT_STAMPS = 12, VT_ITEMS = 24, VT_WGS = 2;
+constexpr int VT_STAMPS = 16, VT_ITEMS = 24, VT_WGS = 2;
 __device__ long long* g_var_trace = nullptr;
 // (inline asm with AMDGPU constraints has to sit in a __device__ function: in the body of a __global__ template the host
 // pass rejects the constraint, silently drops the kernel's host stub and the library no longer loads)
@@ -902,6 +902,7 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
                             }
                         }
                         __syncthreads();
+                        GPT_VT(12);
                         AF a[R];
                         v4 b[R];
 #pragma unroll
@@ -921,6 +922,7 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
                                 ldA(a[i], k4 + i + R);
                             }
                         });
+                        GPT_VT(13);
                         if (limit > p2) {
 #pragma unroll
                             for (int i = 0; i < R; ++i) ldB(b[i], p2 + i);
@@ -934,6 +936,7 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
                                 ldA(a[i], k4 + i + R); ldB(b[i], k4 + i + R);
                             }
                         });
+                        GPT_VT(14);
                         __syncthreads();                                  // the image is free again (next sweep's first fill)
                     } else if constexpr (R == 2) {
                         AF a0, a1;

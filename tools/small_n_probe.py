@@ -18,7 +18,7 @@ sys.path.insert(0, ROOT)
 from gaussian_process_transportation_amd import _lib  # noqa: E402
 
 PEAK = 78.6e12
-VT_STAMPS, VT_ITEMS, VT_WGS = 12, 24, 2
+VT_STAMPS, VT_ITEMS, VT_WGS = 16, 24, 2
 PHASES = ["item start->block barrier/fence", "->sweep set-up + first fill", "->A ring + barrier", "->lock-step chunks",
           "->diagonal tile (reload sweeps)", "->fold / partial store", "->GEN: scratch visible + barrier", "->slot epilogue"]
 
@@ -90,6 +90,14 @@ def main():
                         d = [int(s[i + 1] - s[i]) if s[i + 1] and s[i] else 0 for i in range(8)]
                         op = f"  [opening: to sweep entry +{int(s[11] - s[1])}, queries +{int(s[9] - s[11])}, diag image +{int(s[10] - s[9])}, first fill +{int(s[2] - s[10])}]" if s[9] and s[10] else ""
                         print(f"    item {it:2d} wave {w}: start +{int(s[0] - t0):8d} | " + " ".join(f"{x:7d}" for x in d) + f" | total {int(s[8] - s[0]):8d}" + op)
+                    if tr[wi, 0, it, 12]:                # HALF instantiation: the diagonal tile per wave (row groups 0 .. 7)
+                        rows = []
+                        for w in range(8):
+                            s = tr[wi, w, it]
+                            g = w if w < 4 else 11 - w
+                            rows.append((g, int(s[12] - s[4]), int(s[13] - s[12]), int(s[14] - s[13]), int(s[5] - s[14])))
+                        print("      diagonal tile, row group: image staged | k-steps < 64 (B from LDS) | k-steps >= 64 (B from scratch) | wait at the barrier:  "
+                              + "  ".join(f"g{g}: {a} | {b} | {c} | {d}" for g, a, b, c, d in sorted(rows)))
                 print("    columns: " + " | ".join(PHASES))
 
 
