@@ -17,9 +17,9 @@
  *     the message of the last failure on the calling thread
  *   - one handle = one fitted model on one GPU; a handle is not thread-safe, but different handles may be used from
  *     different threads at the same time (the hyper-parameter search drives its independent restarts that way)
- *   - D (input dims) in 1..8: D <= 3 (the reference's transport problems are 2-D and 3-D) is the tuned layout, D = 4..8
- *     runs on a wider source layout with the same entry points and results (the reference's regressor is
- *     dimension-agnostic; D > 8 is refused with GPT_E_ARG); O (outputs) >= 1; length_scale has 1 (isotropic) or D entries
+ *   - D (input dims) in 1..15: D <= 3 (the reference's transport problems are 2-D and 3-D) is the tuned layout, D = 4..8 and
+ *     9..15 run on wider source layouts (rows of 8 / 16) with the same entry points and results (the reference's regressor is
+ *     dimension-agnostic; D > 15 is refused with GPT_E_ARG); O (outputs) >= 1; length_scale has 1 (isotropic) or D entries
  */
 #ifndef GPT_HIP_H
 #define GPT_HIP_H
