@@ -27,7 +27,7 @@ h = _lib.Handle(0)
 for it in range(cases):
     N = int(rng.choice([1, 2, 5, 17, 63, 64, 65, 130, 257, 511, 513, 777, 1025, 1500, 2100, 3000]))
     M = int(rng.choice([1, 7, 64, 65, 300, 1000, 4097, 17000, 40000]))      # cut sweeps only / whole rounds + tail
-    D = int(rng.integers(1, 9)) if rng.integers(0, 3) else int(rng.integers(1, 4))      # 4 .. 8: the wide layout
+    D = int(rng.integers(1, 16)) if rng.integers(0, 3) else int(rng.integers(1, 4))      # 4 .. 8 and 9 .. 15: the wide layouts
     O = int(rng.integers(1, 7))
     kind = str(rng.choice(["rbf", "rbf", "rbf", "matern12", "matern32", "matern52"]))
     iso = bool(rng.integers(0, 2))
