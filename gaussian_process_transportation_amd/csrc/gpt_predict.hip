@@ -845,6 +845,7 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
                         for (int j = 0; j < 8; ++j) img[(w + 8 * (8 * half + j)) * 64 + lane] = r[j];
                     }
                     __syncthreads();
+                    GPT_VT(12);
                     v4 b_nxt = img[d_lo * 64 + lane];
                     tri_loop(std::integral_constant<int, DP>{}, d_lo, limit > d_lo ? limit : d_lo, tri, [&](auto jtag, const int k4) {
 #pragma unroll
@@ -856,6 +857,7 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
                             ldA(a[i], k4 + i + DP);
                         }
                     });
+                    GPT_VT(14);
                     __syncthreads();                                     // the image is free again (next sweep's first fill)
                 } else {
                     // fp64: A from Wf and B straight from the scratch image, both one MFMA block (1024 cycles) ahead; program

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--shapes", default="1024x49152,1024x50000,1024x4096,2500x460,2500x4096,2500x10000,2500x16384,2500x49152")
     ap.add_argument("--reps", type=int, default=9)
     ap.add_argument("--jac", action="store_true", help="mean + var + Jacobian (the DESIGN small-batch table) instead of mean + var")
+    ap.add_argument("--f32", action="store_true", help="fp32 model (k_var<float>: the diagonal tile's image goes through LDS); the floor is then quoted on the fp32 peak")
     ap.add_argument("--trace", action="store_true")
     ap.add_argument("--trace-items", type=int, default=6)
     args = ap.parse_args()
@@ -39,12 +40,15 @@ def main():
         if N not in handles:
             X = rng.uniform(0, 1, (N, 3)); Y = 0.05 * np.sin(4 * X) + 0.01 * rng.standard_normal((N, 3))
             h = _lib.Handle(0)
+            if args.f32:
+                h.set_dtype(_lib.GPT_F32)
             h.fit(X, Y, np.array([0.1] * 3), 0.1, 1e-4, 1e-10)
             handles[N] = h
         h = handles[N]
-        xq = torch.from_numpy(np.random.default_rng(1).uniform(-0.1, 1.1, (M, 3))).cuda()
-        mean = torch.empty((M, 3), dtype=torch.float64, device="cuda"); var = torch.empty(M, dtype=torch.float64, device="cuda")
-        J = torch.empty((M, 3, 3), dtype=torch.float64, device="cuda") if args.jac else None
+        tt = torch.float32 if args.f32 else torch.float64
+        xq = torch.from_numpy(np.random.default_rng(1).uniform(-0.1, 1.1, (M, 3))).to(tt).cuda()
+        mean = torch.empty((M, 3), dtype=tt, device="cuda"); var = torch.empty(M, dtype=tt, device="cuda")
+        J = torch.empty((M, 3, 3), dtype=tt, device="cuda") if args.jac else None
         call = lambda: h.predict_all_dev(xq.data_ptr(), M, mean.data_ptr(), var.data_ptr(), J.data_ptr() if J is not None else 0, 0, 0)
         for _ in range(3):
             call()
@@ -56,8 +60,8 @@ def main():
             t = h.predict_timings()
             vms.append(t["var_ms"]); mms.append(t["mean_jac_ms"])
         h.set_profiling(False)
-        v = float(np.median(vms)); floor = M * (N * N + 2 * N) / PEAK * 1e3
-        print(f"[{lib_tag}] N={N} M={M}: k_var {v:.4f} ms (min {min(vms):.4f})  floor {floor:.4f} ms  = {floor / v * 100:.1f} % of the fp64 MFMA peak;"
+        v = float(np.median(vms)); floor = M * (N * N + 2 * N) / (157.3e12 if args.f32 else PEAK) * 1e3
+        print(f"[{lib_tag}] N={N} M={M}: k_var {v:.4f} ms (min {min(vms):.4f})  floor {floor:.4f} ms  = {floor / v * 100:.1f} % of the {'fp32' if args.f32 else 'fp64'} MFMA peak;"
               f"  mean{'+J' if args.jac else ''} kernel {np.median(mms):.4f} ms", flush=True)
         if args.trace:
             n_ph = VT_WGS * 8 * VT_ITEMS * VT_STAMPS
@@ -90,7 +94,15 @@ def main():
                         d = [int(s[i + 1] - s[i]) if s[i + 1] and s[i] else 0 for i in range(8)]
                         op = f"  [opening: to sweep entry +{int(s[11] - s[1])}, queries +{int(s[9] - s[11])}, diag image +{int(s[10] - s[9])}, first fill +{int(s[2] - s[10])}]" if s[9] and s[10] else ""
                         print(f"    item {it:2d} wave {w}: start +{int(s[0] - t0):8d} | " + " ".join(f"{x:7d}" for x in d) + f" | total {int(s[8] - s[0]):8d}" + op)
-                    if tr[wi, 0, it, 12]:                # HALF instantiation: the diagonal tile per wave (row groups 0 .. 7)
+                    if tr[wi, 0, it, 12] and args.f32:   # fp32: image copied to LDS | the wave's k-steps | wait at the barrier
+                        rows = []
+                        for w in range(8):
+                            s = tr[wi, w, it]
+                            g = w if w < 4 else 11 - w
+                            rows.append((g, int(s[12] - s[4]), int(s[14] - s[12]), int(s[5] - s[14])))
+                        print("      diagonal tile, row group: image copied to LDS | its k-steps | wait at the barrier:  "
+                              + "  ".join(f"g{g}: {a} | {b} | {c}" for g, a, b, c in sorted(rows)))
+                    elif tr[wi, 0, it, 12]:              # HALF instantiation: the diagonal tile per wave (row groups 0 .. 7)
                         rows = []
                         for w in range(8):
                             s = tr[wi, w, it]
