@@ -798,6 +798,7 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
                 const v4* bp = buni + (size_t)kd0 * 64;
                 auto ldA = [&](AF& a, const int k) {
                     const int kk = k < limit ? k : limit - 1;            // clamped: redundant, in bounds
+                    if (GPT_ABL == 12 && k >= d_lo + 8) return;          // (timing-only ablation: the tile without its A stream)
                     El<T>::lda(a, ap + (size_t)kk * A_STEP, lane);
                 };
                 // The last 16 k-steps of a wave's range are its own 64 x 64 diagonal block of the factor (when the item's range reaches
@@ -852,7 +853,7 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
                         for (int i = 0; i < DP; ++i) {
                             const v4 b = b_nxt;
                             const int kn = (k4 + i + 1 < limit) ? (k4 + i + 1) : (limit - 1);
-                            b_nxt = img[kn * 64 + lane];
+                            if (GPT_ABL != 13) b_nxt = img[kn * 64 + lane];          // (13: timing-only, the tile without its B reads)
                             El<T>::template mfma_from<decltype(jtag)::value>(acc, a[i], b);
                             ldA(a[i], k4 + i + DP);
                         }
@@ -866,6 +867,7 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
                     // fewer fetched bytes: profiles/r02_kvar_diag_image_fp64.txt.)
                     auto ldB = [&](v4& b, const int k) {
                         const int kk = k < limit ? k : limit - 1;
+                        if (GPT_ABL == 13 && k >= d_lo + 8) return;
                         b = (bp + (size_t)kk * 64)[lane];
                     };
                     // (2: the round-1 .. 3 loop, kept for A/B — and for the 3-column kernel, whose generating side keeps more state alive:
