@@ -306,15 +306,17 @@ void launch_mean_jac(hipStream_t s, const KernelParams& p, const void* Xs, const
 //     entirely above the diagonal (wave g has 16 (g + 1) of 128), row groups paired (0,7)(1,6)(2,5)(3,4) on
 //     the SIMDs.  In the reload sweeps the diagonal tile runs OUTSIDE the lock-step LDS pipeline (every wave
 //     on its own, B straight from the scratch image), so the pairing balances it: 0.56 of a full tile
-//     instead of 0.75 (+2.7 %);
-//   * work split: gpt_plan.h (rounds of whole blocks, then an explicit item list cut at tile granularity).
+//     instead of 0.75 (+2.7 %) — since round 4 in every sweep, and 0.52: the last 16 k-steps of a wave's range are its own lower-
+//     triangular 64 x 64 block, whose zero 16 x 16 blocks get no MFMA (GPT_DIAG_TRIANGLE);
+//   * work split: gpt_plan.h (rounds of whole blocks, then an explicit item list cut at quarter tiles — inside diagonal tiles
+//     too where a workgroup's share is small).
 // Alternatives measured and dropped (profiles/r01_kvar_variant_ab.txt): per-wave B generation (v1, 53 TF),
 // 8-step chunks (-3.7 %), barrier-free sweeps with every wave reading B from the scratch image (-3 %: L2
 // hit rate 97 % -> 56 %, 3.4 TB/s from beyond L2, clock 2.18 GHz), deeper A prefetch (0 %).
 // NCOMP = 1: one column per query (k*).  NCOMP = 4: four columns per query (k*, dk_0, dk_1, dk_2).
 // NCOMP = 3: D columns per query (dk_0 .. dk_{D-1}) — the Jacobian variance without the variance.
-// DW = 3 is all of the above: D <= 3, source rows of 4 elements, query coordinates in registers.  DW = WIDE_D is the
-// wide path for D = 4 .. 8 (rows of 8): only the generating sweep differs — the block's query coordinates sit in LDS
+// DW = 3 is all of the above: D <= 3, source rows of 4 elements, query coordinates in registers.  DW = WIDE_D / MAX_D is the
+// wide path for D = 4 .. 8 (rows of 8) / 9 .. 15 (rows of 16): only the generating sweep differs — the block's query coordinates sit in LDS
 // (qs[d][query]), distances are coordinate loops — with NCOMP = 1, or NCOMP = 8 / 16: k*, dk_0 .. dk_{D-1} and zero
 // columns up to 8 (D <= 7) or 16 per query, so that a query's columns stay inside one 16-column MFMA tile.  KSTAR = false
 // (wide path, NCOMP = 4 for D = 4 and 8 for D = 8): the Jacobian variance alone, dk_0 .. dk_{D-1} without the k* column —
