@@ -228,7 +228,16 @@ static void launch_mean_jac_t(hipStream_t s, const KernelParams& p, const T* Xs,
 #define GPT_MJ_QPW 2
 #endif
     constexpr int QPW = DW == 3 ? GPT_MJ_QPW : 1;          // queries per wave; 500k queries at N = 8192: 1 -> 9.17 ms, 2 -> 6.19-6.26, 4 -> 6.11 (r3mj)
-    const int64_t waves = (M + QPW - 1) / QPW;
+#ifndef GPT_MJ_QPW_MEAN
+#define GPT_MJ_QPW_MEAN 4
+#endif
+    // the mean alone (no Jacobian sums: 3 accumulators per query instead of 12): more queries per wave when there are waves enough
+    // (M >= 32 768: 8 per SIMD), so that a small model's short source loop (16 iterations at N = 1024) is not dwarfed by the wave's
+    // prologue and its cross-lane reductions.  N = 1024, M = 50 000: 0.071 -> 0.064 ms; at M = 10^4 four per wave LOSE 7 - 10 % (r4s38)
+    constexpr int QPW_M = DW == 3 ? GPT_MJ_QPW_MEAN : 1;
+    const bool many = !J && M >= 32768 && QPW_M != QPW;
+    const int qpw = many ? QPW_M : QPW;
+    const int64_t waves = (M + qpw - 1) / qpw;
     const int64_t blocks = (waves + 3) / 4;
     for (int ob = 0; ob < p.O; ob += 4) {
         const int cnt = (p.O - ob) < 4 ? (p.O - ob) : 4;
@@ -237,6 +246,7 @@ static void launch_mean_jac_t(hipStream_t s, const KernelParams& p, const T* Xs,
 #define GPT_MJ(OC_, KT_)                                                                                                          \
         do {                                                                                                                      \
             if (J) hipLaunchKernelGGL((k_mean_jac<T, QPW, OC_, KT_, DW, true>), grid, dim3(256), 0, s, p, Xs, a4, Xq, M, ob, mean, J); \
+            else if (many) hipLaunchKernelGGL((k_mean_jac<T, QPW_M, OC_, KT_, DW, false>), grid, dim3(256), 0, s, p, Xs, a4, Xq, M, ob, mean, J); \
             else hipLaunchKernelGGL((k_mean_jac<T, QPW, OC_, KT_, DW, false>), grid, dim3(256), 0, s, p, Xs, a4, Xq, M, ob, mean, J);  \
         } while (0)
 #define GPT_MJ_K(OC_)                                     \
