@@ -550,11 +550,16 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
             if (GEN) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }      // (trace builds: the query coordinates have arrived)
             GPT_VT(9);
 #endif
-            T gx[DW];                                      // coordinates of the source this wave generates next
+            // rows of 16: the source's coordinates are read where they are used (produce_to), four at a time — carried across the MFMA
+            // steps like the narrower rows' they are 32 more registers than the fp64 kernel has, and it spilled inside its loops
+            constexpr bool LATE_X = GEN && WIDE && DW == 16;
+            T gx[LATE_X ? 1 : DW];                         // coordinates of the source this wave generates next
             T gx_own = (T)0;                               // (wide) and the one a derivative column multiplies by
             v4 bl;                                         // or the fragments it reloads next
-            auto load_x_to = [&](const T* xp, T (&ox)[DW], T& oown) {
-                if constexpr (WIDE) {
+            auto load_x_to = [&](const T* xp, auto& ox, T& oown) {
+                if constexpr (LATE_X) {
+                    (void)xp; (void)ox; (void)oown;
+                } else if constexpr (WIDE) {
 #pragma unroll
                     for (int v = 0; v < DW / 4; ++v) {
                         const v4 xv = *reinterpret_cast<const v4*>(xp + 4 * v);
@@ -579,7 +584,34 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
                 constexpr bool to_lds = decltype(lds_tag)::value;
                 constexpr bool staged = decltype(staged_tag)::value;
                 T* dstl = Bs(buf, k4 % VAR_CH);
-                if constexpr (GEN && WIDE) {
+                if constexpr (LATE_X) {
+                    const T* xp = Xs + (size_t)(k4 * 4 + lk) * XS;
+                    const T xo = (NCOMP != 1) ? xp[own_d] * RS2 : (T)0;
+                    v4 b;
+                    T hh[4] = {(T)0, (T)0, (T)0, (T)0}, kv[4];
+#pragma unroll
+                    for (int v = 0; v < DW / 4; ++v) {
+                        const v4 xv = *reinterpret_cast<const v4*>(xp + 4 * v);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const int qi = (16 * t + lc) / (CPQ > 1 ? CPQ : 1);      // this column's query within the block
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { const T df = fma(xv[e], RS2, -qs[4 * v + e][qi]); hh[t] = fma(df, df, hh[t]); }
+                        }
+                    }
+                    if constexpr (staged) kernel_tab4<KT>(hh, lnc, Tt, kv);
+                    else {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) kv[t] = kernel_tab<KT>(hh[t], lnc, Tt);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int qi = (16 * t + lc) / (CPQ > 1 ? CPQ : 1);
+                        b[t] = (NCOMP == 1) ? kv[t] : kv[t] * (cbv + sc_own * (xo - qs[own_d][qi]));
+                    }
+                    if (to_lds && lds_on) *reinterpret_cast<v4*>(dstl) = b;
+                    if (to_scr) (buni + (size_t)k4 * 64)[lane] = b;
+                } else if constexpr (GEN && WIDE) {
                     T x[DW];
 #pragma unroll
                     for (int d = 0; d < DW; ++d) x[d] = gx[d] * RS2;
@@ -658,13 +690,13 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
             auto generate_batch = [&](auto lds_tag, auto cnt_tag, const int buf, const int k4_0, const int stride, const bool to_scr = true,
                                       const bool lds_on = true) {
                 constexpr int cnt = decltype(cnt_tag)::value;
-                T bx[cnt][DW], bo[cnt];
+                T bx[cnt][LATE_X ? 1 : DW], bo[cnt];
 #pragma unroll
                 for (int j = 0; j < cnt; ++j) { bo[j] = (T)0; load_x_to(Xs + (size_t)((k4_0 + j * stride) * 4 + lk) * XS, bx[j], bo[j]); }
 #pragma unroll
                 for (int j = 0; j < cnt; ++j) {
 #pragma unroll
-                    for (int d = 0; d < DW; ++d) gx[d] = bx[j][d];
+                    for (int d = 0; d < (LATE_X ? 1 : DW); ++d) gx[d] = bx[j][d];
                     gx_own = bo[j];
                     produce_to(lds_tag, std::integral_constant<bool, GPT_GEN_STAGED_EXP != 0>{}, buf, k4_0 + j * stride, to_scr, lds_on);
                 }
