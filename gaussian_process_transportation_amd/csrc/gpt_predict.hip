@@ -550,9 +550,10 @@ __global__ __launch_bounds__(512, 2) void k_var(KernelParams p, VarPlanDev pl, c
             if (GEN) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }      // (trace builds: the query coordinates have arrived)
             GPT_VT(9);
 #endif
-            // rows of 16: the source's coordinates are read where they are used (produce_to), four at a time — carried across the MFMA
-            // steps like the narrower rows' they are 32 more registers than the fp64 kernel has, and it spilled inside its loops
-            constexpr bool LATE_X = GEN && WIDE && DW == 16;
+            // rows of 16 (and the wide kernels with cross terms): the source's coordinates are read where they are used (produce_to), four
+            // at a time — carried across the MFMA steps like the narrower rows' they are 16 - 32 more registers than the fp64 kernel has, and
+            // it spilled inside its loops
+            constexpr bool LATE_X = GEN && WIDE && (DW == 16 || CROSS);
             T gx[LATE_X ? 1 : DW];                         // coordinates of the source this wave generates next
             T gx_own = (T)0;                               // (wide) and the one a derivative column multiplies by
             v4 bl;                                         // or the fragments it reloads next
