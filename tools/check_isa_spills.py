@@ -23,13 +23,22 @@ for name in re.findall(r"^(_ZN3gpt5k_varI\w+):", s, flags=re.M):
     j = s.index(".end_amdhsa_kernel", i)
     body = s[i:j]
     vg = re.search(r"\.amdhsa_next_free_vgpr (\d+)", body)
-    blocks, cur = [], []
+    blocks, cur, lab = [], [], "entry"
     for line in body.split("\n"):
         if line.startswith(".LBB"):
-            blocks.append(cur); cur = []
+            blocks.append((lab, cur)); cur = []; lab = line.split(":")[0]
         cur.append(line)
-    blocks.append(cur)
-    hot = [b for b in blocks if sum("v_mfma" in x for x in b) >= 64 and not any("v_exp" in x or "v_ldexp" in x for x in b)]
+    blocks.append((lab, cur))
+    # hot: the ring loops of the diagonal tile (a block that branches to itself, 64 MFMAs) and the sub-chunks of the lock-step part
+    # (128 MFMAs each, inside the chunk loop).  The peeled last steps of a diagonal tile (96 / 64 / 32 MFMAs, straight-line, once per
+    # tile) are not.
+    def is_hot(lab, b):
+        n = sum("v_mfma" in x for x in b)
+        if any("v_exp" in x or "v_ldexp" in x for x in b):
+            return False
+        self_loop = any(("s_cbranch" in x or "s_branch" in x) and lab in x for x in b)
+        return (n >= 64 and self_loop) or n >= 128
+    hot = [b for lab, b in blocks if is_hot(lab, b)]
     spilled = [sum("scratch_" in x for x in b) for b in hot]
     tag = re.search(r"k_varI(\w)Li(\d+)ELb(\d)ELi(\d)ELi(\d+)ELb(\d)ELb(\d)", name).groups()
     total_scratch = sum("scratch_" in x for x in body.split("\n"))
